@@ -1,0 +1,596 @@
+// brn_api.cpp — the extern "C" boundary (include/birefnet_hip.h).  Exceptions stop here; every entry returns a status
+// and leaves a thread-local message for brn_last_error().
+#include "brn_host.h"
+#include <cstring>
+#include <cstdio>
+#include <cmath>
+#include <functional>
+#include <memory>
+
+namespace brn {
+const char* last_error_cstr();
+
+template <class F>
+static brn_status guarded(F&& f) {
+    try {
+        f();
+        return BRN_OK;
+    } catch (const Error& e) {
+        set_last_error(e.what());
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        set_last_error("host allocation failed");
+        return BRN_ERR_OOM;
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return BRN_ERR_INVALID_ARG;
+    }
+}
+
+// per-call staging of caller buffers: BRN_MEM_HOST buffers travel through temporary HBM allocations
+struct Staging {
+    hipStream_t s; brn_mem loc;
+    std::vector<void*> tmp;
+    struct Out { float* host; float* dev; size_t n; };
+    std::vector<Out> outs;
+    Staging(void* stream, brn_mem l) : s((hipStream_t)stream), loc(l) {}
+    float* dalloc(size_t n) {
+        void* d = nullptr;
+        hipError_t e = hipMalloc(&d, n * sizeof(float) + 16);
+        if (e != hipSuccess) fail(BRN_ERR_OOM, "hipMalloc of %zu bytes failed: %s", n * sizeof(float), hipGetErrorString(e));
+        tmp.push_back(d);
+        return (float*)d;
+    }
+    const float* in(const float* p, size_t n) {
+        if (!p) fail(BRN_ERR_INVALID_ARG, "null input pointer");
+        if (loc == BRN_MEM_DEVICE) return p;
+        float* d = dalloc(n);
+        BRN_HIP(hipMemcpyAsync(d, p, n * sizeof(float), hipMemcpyHostToDevice, s));
+        return d;
+    }
+    float* out(float* p, size_t n) {
+        if (!p) fail(BRN_ERR_INVALID_ARG, "null output pointer");
+        if (loc == BRN_MEM_DEVICE) return p;
+        float* d = dalloc(n);
+        outs.push_back({p, d, n});
+        return d;
+    }
+    void finish() {
+        for (auto& o : outs) BRN_HIP(hipMemcpyAsync(o.host, o.dev, o.n * sizeof(float), hipMemcpyDeviceToHost, s));
+        if (loc == BRN_MEM_HOST) BRN_HIP(hipStreamSynchronize(s));
+    }
+    ~Staging() {
+        if (!tmp.empty()) (void)hipStreamSynchronize(s);
+        for (void* p : tmp) (void)hipFree(p);
+    }
+};
+
+// run a graph fragment with a private arena: plan (dry), allocate, run
+static void with_arena(hipStream_t s, const std::function<void(Ctx&)>& fn) {
+    Arena a;
+    a.dry = true;
+    Ctx c{&a, s, true, false, nullptr, nullptr, nullptr};
+    fn(c);
+    Arena real;
+    real.cap = a.peak + 256;
+    void* d = nullptr;
+    hipError_t e = hipMalloc(&d, real.cap);
+    if (e != hipSuccess) fail(BRN_ERR_OOM, "workspace hipMalloc of %zu bytes failed: %s", real.cap, hipGetErrorString(e));
+    real.base = (char*)d;
+    Ctx c2{&real, s, false, false, nullptr, nullptr, nullptr};
+    try {
+        fn(c2);
+        BRN_HIP(hipStreamSynchronize(s));
+    } catch (...) {
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(d);
+        throw;
+    }
+    (void)hipFree(d);
+}
+
+static void plan_model(Model& m, int B, int H, int W) {
+    if (B <= m.plan_B && H <= m.plan_H && W <= m.plan_W && m.arena.base) return;
+    const int pb = B > m.plan_B ? B : m.plan_B, ph = H > m.plan_H ? H : m.plan_H, pw = W > m.plan_W ? W : m.plan_W;
+    Arena dry;
+    dry.dry = true;
+    Ctx c{&dry, nullptr, true, false, nullptr, nullptr, nullptr};
+    model_forward(m, c, nullptr, pb, ph, pw, nullptr, 0);
+    size_t need = dry.peak + 4096;
+    // staging for host-resident input / output of the full model
+    need += ((size_t)pb * 3 * ph * pw + (size_t)pb * ph * pw) * sizeof(float) + 1024;
+    if (m.arena.base) { BRN_HIP(hipDeviceSynchronize()); (void)hipFree(m.arena.base); m.arena.base = nullptr; }
+    void* d = nullptr;
+    hipError_t e = hipMalloc(&d, need);
+    if (e != hipSuccess) fail(BRN_ERR_OOM, "workspace hipMalloc of %zu bytes (B=%d, %dx%d) failed: %s", need, pb, ph, pw, hipGetErrorString(e));
+    m.arena.base = (char*)d; m.arena.cap = need; m.arena.top = 0; m.arena.peak = 0; m.arena.dry = false;
+    m.plan_B = pb; m.plan_H = ph; m.plan_W = pw;
+}
+
+static void collect_profile(Model& m, hipStream_t s) {
+    BRN_HIP(hipStreamSynchronize(s));
+    for (int f = 0; f < FAM_COUNT; ++f) { m.fam_launches[f] = 0; m.fam_ms[f] = 0.f; m.fam_flop[f] = 0.0; m.fam_bytes[f] = 0.0; }
+    for (auto& r : m.records) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) ms = 0.f;
+        m.fam_launches[r.fam]++; m.fam_ms[r.fam] += ms; m.fam_flop[r.fam] += r.flop; m.fam_bytes[r.fam] += r.bytes;
+    }
+    if (m.stage_ev_ok) {
+        for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&m.last_ms[i], m.stage_ev[i], m.stage_ev[i + 1]);
+        (void)hipEventElapsedTime(&m.last_ms[4], m.stage_ev[0], m.stage_ev[4]);
+    }
+}
+
+static void validate_config(const brn_config& c) {
+    const int bc[4] = {192, 384, 768, 1536};
+    for (int i = 0; i < 4; ++i)
+        if (c.backbone_channels[i] != bc[i] || c.backbone_channels[i] != (c.embed_dim << i))
+            fail(BRN_ERR_INVALID_ARG, "backbone_channels/embed_dim must be the Swin-L plan [192,384,768,1536]: the decoder's ipt blocks "
+                 "hard-wire it (birefnet.rs:189-193)");
+    if (!c.mul_scl_ipt || c.n_cxt != 3 || c.cxt[0] != 192 || c.cxt[1] != 384 || c.cxt[2] != 768)
+        fail(BRN_ERR_INVALID_ARG, "only mul_scl_ipt=true with cxt=[192,384,768] is supported (the reference decoder's channel plan "
+             "is inconsistent otherwise, birefnet.rs:176-207)");
+    if (c.deform_mode != BRN_DEFORM_REFERENCE_CPU && c.deform_mode != BRN_DEFORM_DEFORMABLE)
+        fail(BRN_ERR_INVALID_ARG, "unknown deform_mode %d", c.deform_mode);
+    for (int i = 0; i < 4; ++i)
+        if (c.depths[i] < 1 || c.depths[i] > 64) fail(BRN_ERR_INVALID_ARG, "depths[%d]=%d out of range", i, c.depths[i]);
+}
+
+static void run_model(Model* m, const float* x, int B, int H, int W, brn_mem in_loc, float* out, brn_mem out_loc, void* stream,
+                      int apply_sigmoid) {
+    if (!m || !x || !out) fail(BRN_ERR_INVALID_ARG, "null argument");
+    if (B < 1) fail(BRN_ERR_INVALID_ARG, "batch must be >= 1");
+    std::lock_guard<std::mutex> lk(m->mu);
+    BRN_HIP(hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    plan_model(*m, B, H, W);
+    m->arena.top = 0;
+    const size_t n_in = (size_t)B * 3 * H * W, n_out = (size_t)B * H * W;
+    const float* dx = x;
+    float* dout = out;
+    if (in_loc == BRN_MEM_HOST) {
+        float* t = m->arena.alloc(n_in);
+        BRN_HIP(hipMemcpyAsync(t, x, n_in * sizeof(float), hipMemcpyHostToDevice, s));
+        dx = t;
+    }
+    if (out_loc == BRN_MEM_HOST) dout = m->arena.alloc(n_out);
+    m->records.clear(); m->event_next = 0;
+    if (m->profiling && !m->stage_ev_ok) {
+        for (int i = 0; i < 6; ++i) BRN_HIP(hipEventCreate(&m->stage_ev[i]));
+        m->stage_ev_ok = true;
+    }
+    Ctx c{&m->arena, s, false, m->profiling, &m->records, &m->event_pool, &m->event_next};
+    model_forward(*m, c, dx, B, H, W, dout, apply_sigmoid);
+    if (out_loc == BRN_MEM_HOST) {
+        BRN_HIP(hipMemcpyAsync(out, dout, n_out * sizeof(float), hipMemcpyDeviceToHost, s));
+        BRN_HIP(hipStreamSynchronize(s));
+    }
+    if (m->profiling) collect_profile(*m, s);
+}
+
+}  // namespace brn
+
+using namespace brn;
+
+struct brn_model { Model m; };
+struct brn_swin { brn_config cfg; int device; DeviceOwner own; SwinW w; std::mutex mu; };
+
+extern "C" {
+
+int brn_abi_version(void) { return BRN_ABI_VERSION; }
+const char* brn_last_error(void) { return last_error_cstr(); }
+const char* brn_build_info(void) {
+#define BRN_STR2(x) #x
+#define BRN_STR(x) BRN_STR2(x)
+    return "libbirefnet_hip gfx950 (CDNA4) fp32 MFMA path; HIP " BRN_STR(HIP_VERSION_MAJOR) "." BRN_STR(HIP_VERSION_MINOR) "." BRN_STR(HIP_VERSION_PATCH);
+}
+brn_status brn_device_count(int* n) {
+    return guarded([&] {
+        if (!n) fail(BRN_ERR_INVALID_ARG, "null argument");
+        int k = 0;
+        hipError_t e = hipGetDeviceCount(&k);
+        *n = (e == hipSuccess) ? k : 0;
+    });
+}
+
+void brn_config_default_swin_l(brn_config* c) {
+    if (!c) return;
+    memset(c, 0, sizeof *c);
+    c->size_w = 1024; c->size_h = 1024;                       // birefnet.rs:35
+    strncpy(c->backbone, "swin_v1_l", sizeof c->backbone - 1);  // birefnet.rs:36
+    const int bc[4] = {192, 384, 768, 1536};                   // birefnet.rs:38
+    const int dp[4] = {2, 2, 18, 2}, nh[4] = {6, 12, 24, 48};  // swin.rs:72-73
+    for (int i = 0; i < 4; ++i) { c->backbone_channels[i] = bc[i]; c->depths[i] = dp[i]; c->num_heads[i] = nh[i]; }
+    c->mul_scl_ipt = 1; c->ms_supervision = 1; c->dec_ipt = 1; c->use_aspp_deformable = 1;   // birefnet.rs:39-42
+    c->cxt[0] = 192; c->cxt[1] = 384; c->cxt[2] = 768; c->n_cxt = 3;                          // birefnet.rs:43
+    c->embed_dim = 192; c->window_size = 12; c->mlp_ratio = 4.0f; c->patch_size = 4; c->in_channels = 3;
+    c->drop_path_rate = 0.2f;                                  // swin.rs:71-78
+    c->deform_mode = BRN_DEFORM_REFERENCE_CPU;
+}
+void brn_config_lateral_channels(const brn_config* c, int out[4]) {
+    const int mult = c->mul_scl_ipt ? 2 : 1;                   // birefnet.rs:51
+    for (int i = 0; i < 4; ++i) out[i] = c->backbone_channels[i] * mult;
+}
+int brn_config_x4_channels(const brn_config* c) {
+    const int mult = c->mul_scl_ipt ? 2 : 1;                   // birefnet.rs:57-60
+    int s = c->backbone_channels[3] * mult;
+    for (int i = 0; i < c->n_cxt; ++i) s += c->cxt[i] * mult;
+    return s;
+}
+
+brn_status brn_model_create(const brn_config* cfg, const brn_named_tensor* weights, size_t n, int device, brn_dtype dt,
+                            int max_batch, int max_h, int max_w, brn_model** out) {
+    return guarded([&] {
+        if (!cfg || !weights || !out) fail(BRN_ERR_INVALID_ARG, "null argument");
+        if (dt != BRN_F32) fail(BRN_ERR_INVALID_ARG, "unsupported compute dtype %d (this build computes in fp32)", (int)dt);
+        *out = nullptr;
+        ensure_device(device);
+        validate_config(*cfg);
+        std::unique_ptr<brn_model> h(new brn_model());
+        Model& m = h->m;
+        m.cfg = *cfg; m.device = device;
+        WeightTable wt(weights, n);
+        build_swin_weights(wt, "bb.", *cfg, m.own, m.swin);                               // birefnet.rs:393
+        int lat[4];
+        brn_config_lateral_channels(cfg, lat);
+        build_decblk_weights(wt, "squeeze_module.0.", brn_config_x4_channels(cfg), lat[3], cfg->deform_mode, m.own, m.squeeze);   // birefnet.rs:397-399
+        build_decoder_weights(wt, "decoder.", *cfg, m.own, m.dec);                        // birefnet.rs:401
+        m.has_decoder = true;
+        if (max_batch > 0 && max_h > 0 && max_w > 0) plan_model(m, max_batch, max_h, max_w);
+        *out = h.release();
+    });
+}
+void brn_model_destroy(brn_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->m.device);
+    (void)hipDeviceSynchronize();
+    delete m;
+}
+
+brn_status brn_forward_logits(brn_model* m, const float* x, int B, int H, int W, brn_mem in_loc, float* out, brn_mem out_loc,
+                              void* stream) {
+    return guarded([&] { run_model(m ? &m->m : nullptr, x, B, H, W, in_loc, out, out_loc, stream, 0); });
+}
+brn_status brn_forward(brn_model* m, const float* x, int B, int H, int W, brn_mem in_loc, float* out, brn_mem out_loc,
+                       void* stream) {
+    return guarded([&] { run_model(m ? &m->m : nullptr, x, B, H, W, in_loc, out, out_loc, stream, 1); });
+}
+
+brn_status brn_model_set_profiling(brn_model* m, int enable) {
+    return guarded([&] {
+        if (!m) fail(BRN_ERR_INVALID_ARG, "null model");
+        std::lock_guard<std::mutex> lk(m->m.mu);
+        m->m.profiling = enable != 0;
+    });
+}
+brn_status brn_model_last_timings(brn_model* m, float ms[5]) {
+    return guarded([&] {
+        if (!m || !ms) fail(BRN_ERR_INVALID_ARG, "null argument");
+        for (int i = 0; i < 5; ++i) ms[i] = m->m.last_ms[i];
+    });
+}
+brn_status brn_model_last_kernel_stats(brn_model* m, int n, int* launches, float* ms, double* flop, double* bytes, int* n_out) {
+    return guarded([&] {
+        if (!m || !launches || !ms || !flop || !bytes) fail(BRN_ERR_INVALID_ARG, "null argument");
+        const int k = n < FAM_COUNT ? n : FAM_COUNT;
+        for (int f = 0; f < k; ++f) {
+            launches[f] = m->m.fam_launches[f]; ms[f] = m->m.fam_ms[f]; flop[f] = m->m.fam_flop[f]; bytes[f] = m->m.fam_bytes[f];
+        }
+        if (n_out) *n_out = FAM_COUNT;
+    });
+}
+const char* brn_kernel_family_name(int f) {
+    static const char* names[FAM_COUNT] = {"gemm_dense", "gemm_conv_nhwc", "gemm_gather_nchw", "gemm_deform_nhwc",
+                                           "window_attention", "layernorm", "resize", "elementwise"};
+    return (f >= 0 && f < FAM_COUNT) ? names[f] : "?";
+}
+
+// ---- pieces of the model used individually by bench_inference.rs -------------------------------------------------------
+static void swin_outputs_nchw(Ctx& c, const SwinW& w, const float* dx, int B, int H, int W, float* const douts[4]) {
+    int hs[4], ws[4];
+    swin_stage_dims(H, W, w.patch, hs, ws);
+    Map hm[4];
+    for (int i = 0; i < 4; ++i) hm[i] = new_map(c, B, hs[i], ws[i], w.embed_dim << i);
+    swin_forward(c, w, dx, B, H, W, hm);
+    if (!c.dry)
+        for (int i = 0; i < 4; ++i)     // NHWC -> NCHW: the permute(0,3,1,2) of swin.rs:786-788
+            BRN_HIP(launch_nhwc_to_nchw(hm[i].p, B, hm[i].C, hs[i], ws[i], hm[i].ld, 0, douts[i], c.stream));
+}
+
+static void swin_entry(const SwinW& w, int device, const float* x, int B, int H, int W, brn_mem in_loc, float* const outs[4],
+                       brn_mem out_loc, void* stream) {
+    if (!x || !outs) fail(BRN_ERR_INVALID_ARG, "null argument");
+    if (B < 1 || H < 1 || W < 1) fail(BRN_ERR_INVALID_ARG, "bad input shape");
+    BRN_HIP(hipSetDevice(device));
+    Staging si(stream, in_loc), so(stream, out_loc);
+    const float* dx = si.in(x, (size_t)B * 3 * H * W);
+    int hs[4], ws[4];
+    swin_stage_dims(H, W, w.patch, hs, ws);
+    float* douts[4];
+    for (int i = 0; i < 4; ++i) douts[i] = so.out(outs[i], (size_t)B * (w.embed_dim << i) * hs[i] * ws[i]);
+    with_arena((hipStream_t)stream, [&](Ctx& c) { swin_outputs_nchw(c, w, dx, B, H, W, douts); });
+    so.finish();
+}
+
+brn_status brn_model_backbone_forward(brn_model* m, const float* x, int B, int H, int W, brn_mem in_loc, float* const outs[4],
+                                      brn_mem out_loc, void* stream) {
+    return guarded([&] {
+        if (!m) fail(BRN_ERR_INVALID_ARG, "null model");
+        std::lock_guard<std::mutex> lk(m->m.mu);
+        swin_entry(m->m.swin, m->m.device, x, B, H, W, in_loc, outs, out_loc, stream);
+    });
+}
+
+brn_status brn_model_squeeze_forward(brn_model* m, const float* x4, int B, int h, int w, brn_mem in_loc, float* out,
+                                     brn_mem out_loc, void* stream) {
+    return guarded([&] {
+        if (!m || !x4 || !out) fail(BRN_ERR_INVALID_ARG, "null argument");
+        std::lock_guard<std::mutex> lk(m->m.mu);
+        BRN_HIP(hipSetDevice(m->m.device));
+        const int cin = m->m.squeeze.cin, cout = m->m.squeeze.cout;
+        Staging si(stream, in_loc), so(stream, out_loc);
+        const float* dx = si.in(x4, (size_t)B * cin * h * w);
+        float* dy = so.out(out, (size_t)B * cout * h * w);
+        with_arena((hipStream_t)stream, [&](Ctx& c) {
+            Map X = new_map(c, B, h, w, cin), Y = new_map(c, B, h, w, cout);
+            if (!c.dry) BRN_HIP(launch_nchw_to_nhwc(dx, B, cin, h, w, X.p, X.ld, 0, c.stream));
+            decblk_forward(c, m->m.squeeze, X, Y, m->m.cfg.deform_mode);
+            if (!c.dry) BRN_HIP(launch_nhwc_to_nchw(Y.p, B, cout, h, w, Y.ld, 0, dy, c.stream));
+        });
+        so.finish();
+    });
+}
+
+brn_status brn_model_decoder_forward(brn_model* m, const float* x, const float* x1, const float* x2, const float* x3,
+                                     const float* x4, int B, int H, int W, brn_mem in_loc, float* out, brn_mem out_loc,
+                                     void* stream) {
+    return guarded([&] {
+        if (!m || !x || !x1 || !x2 || !x3 || !x4 || !out) fail(BRN_ERR_INVALID_ARG, "null argument");
+        if (H % 32 || W % 32 || H < 32 || W < 32) fail(BRN_ERR_INVALID_ARG, "H and W must be positive multiples of 32");
+        std::lock_guard<std::mutex> lk(m->m.mu);
+        BRN_HIP(hipSetDevice(m->m.device));
+        Staging si(stream, in_loc), so(stream, out_loc);
+        const int hh[4] = {H / 4, H / 8, H / 16, H / 32}, ww[4] = {W / 4, W / 8, W / 16, W / 32};
+        const int ch[4] = {384, 768, 1536, 3072};
+        const float* src[4] = {x1, x2, x3, x4};
+        const float* dsrc[4];
+        for (int i = 0; i < 4; ++i) dsrc[i] = si.in(src[i], (size_t)B * ch[i] * hh[i] * ww[i]);
+        const float* dx = si.in(x, (size_t)B * 3 * H * W);
+        float* dy = so.out(out, (size_t)B * H * W);
+        with_arena((hipStream_t)stream, [&](Ctx& c) {
+            Map X1 = new_map(c, B, hh[0], ww[0], 384), X2 = new_map(c, B, hh[1], ww[1], 768), X3 = new_map(c, B, hh[2], ww[2], 1536);
+            Map D4 = new_map(c, B, hh[3], ww[3], 3456);
+            if (!c.dry) {
+                BRN_HIP(launch_nchw_to_nhwc(dsrc[0], B, 384, hh[0], ww[0], X1.p, X1.ld, 0, c.stream));
+                BRN_HIP(launch_nchw_to_nhwc(dsrc[1], B, 768, hh[1], ww[1], X2.p, X2.ld, 0, c.stream));
+                BRN_HIP(launch_nchw_to_nhwc(dsrc[2], B, 1536, hh[2], ww[2], X3.p, X3.ld, 0, c.stream));
+                BRN_HIP(launch_nchw_to_nhwc(dsrc[3], B, 3072, hh[3], ww[3], D4.p, D4.ld, 0, c.stream));
+            }
+            decoder_forward(c, m->m, dx, B, H, W, X1, X2, X3, D4, dy, 0);
+        });
+        so.finish();
+    });
+}
+
+// ---- stand-alone SwinTransformer -----------------------------------------------------------------------------------------
+brn_status brn_swin_create(const brn_config* cfg, const brn_named_tensor* weights, size_t n, const char* prefix, int device,
+                           brn_swin** out) {
+    return guarded([&] {
+        if (!cfg || !weights || !out) fail(BRN_ERR_INVALID_ARG, "null argument");
+        *out = nullptr;
+        ensure_device(device);
+        std::unique_ptr<brn_swin> h(new brn_swin());
+        h->cfg = *cfg; h->device = device;
+        WeightTable wt(weights, n);
+        build_swin_weights(wt, prefix ? prefix : "", *cfg, h->own, h->w);
+        *out = h.release();
+    });
+}
+void brn_swin_destroy(brn_swin* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    (void)hipDeviceSynchronize();
+    delete s;
+}
+brn_status brn_swin_forward(brn_swin* s, const float* x, int B, int H, int W, brn_mem in_loc, float* const outs[4],
+                            brn_mem out_loc, void* stream) {
+    return guarded([&] {
+        if (!s) fail(BRN_ERR_INVALID_ARG, "null handle");
+        std::lock_guard<std::mutex> lk(s->mu);
+        swin_entry(s->w, s->device, x, B, H, W, in_loc, outs, out_loc, stream);
+    });
+}
+
+// ---- op-level entry points (weights are always host pointers; x / y / residual follow `loc`) -------------------------------------
+brn_status brn_linear_forward(const float* x, int M, int K, const float* w, const float* bias, int N, int act,
+                              const float* residual, float* y, brn_mem loc, int device, void* stream) {
+    return guarded([&] {
+        if (!x || !w || !y || M < 1 || N < 1 || K < 1) fail(BRN_ERR_INVALID_ARG, "bad argument");
+        ensure_device(device);
+        DeviceOwner own;
+        GemmW g = make_linear(own, w, bias, N, K);
+        g.act = act;
+        Staging st(stream, loc);
+        const float* dx = st.in(x, (size_t)M * K);
+        const float* dr = residual ? st.in(residual, (size_t)M * N) : nullptr;
+        float* dy = st.out(y, (size_t)M * N);
+        with_arena((hipStream_t)stream, [&](Ctx& c) { run_gemm(c, g, dx, M, K, dy, N, 0, dr, N, 0); });
+        st.finish();
+    });
+}
+
+brn_status brn_layer_norm_forward(const float* x, int rows, int C, const float* gamma, const float* beta, float eps, float* y,
+                                  brn_mem loc, int device, void* stream) {
+    return guarded([&] {
+        if (!x || !gamma || !beta || !y || rows < 1) fail(BRN_ERR_INVALID_ARG, "bad argument");
+        if (C % 4 || C > 3072) fail(BRN_ERR_INVALID_ARG, "layer_norm width %d unsupported (multiple of 4, <= 3072)", C);
+        ensure_device(device);
+        DeviceOwner own;
+        LNW ln; ln.C = C; ln.g = own.upload(gamma, C); ln.b = own.upload(beta, C);
+        Staging st(stream, loc);
+        const float* dx = st.in(x, (size_t)rows * C);
+        float* dy = st.out(y, (size_t)rows * C);
+        LayerNormParams p{};
+        p.x = dx; p.y = dy; p.rows = rows; p.C = C; p.gamma = ln.g; p.beta = ln.b; p.eps = eps; p.ldx = C; p.ldy = C;
+        BRN_HIP(launch_layernorm(p, (hipStream_t)stream));
+        BRN_HIP(hipStreamSynchronize((hipStream_t)stream));
+        st.finish();
+    });
+}
+
+brn_status brn_conv2d_forward(const float* x, int B, int C, int H, int W, const float* w, const float* bias, int O, int kh,
+                              int kw, int stride, int pad, int dil, const float* bn_g, const float* bn_b, const float* bn_m,
+                              const float* bn_v, float bn_eps, int act, float* y, brn_mem loc, int device, void* stream) {
+    return guarded([&] {
+        if (!x || !w || !y || B < 1 || C < 1 || O < 1 || kh < 1 || kw < 1 || stride < 1 || dil < 1 || pad < 0)
+            fail(BRN_ERR_INVALID_ARG, "bad argument");
+        const int Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
+        if (Ho < 1 || Wo < 1) fail(BRN_ERR_INVALID_ARG, "empty conv output");
+        ensure_device(device);
+        DeviceOwner own;
+        const bool nhwc = (C % 32) == 0;
+        GemmW g = nhwc ? make_conv_nhwc(own, w, nullptr, O, C, C, kh, kw, stride, pad, dil)
+                       : make_conv_gather(own, w, nullptr, O, C, kh, kw, stride, pad, dil);
+        if (bn_g) fold_bn(own, g, bias, bn_g, bn_b, bn_m, bn_v, bn_eps);
+        else if (bias) g.bias = own.upload(bias, O);
+        g.act = act;
+        Staging st(stream, loc);
+        const float* dx = st.in(x, (size_t)B * C * H * W);
+        float* dy = st.out(y, (size_t)B * O * Ho * Wo);
+        with_arena((hipStream_t)stream, [&](Ctx& c) {
+            Map Y = new_map(c, B, Ho, Wo, O);
+            if (nhwc) {
+                Map X = new_map(c, B, H, W, C);
+                if (!c.dry) BRN_HIP(launch_nchw_to_nhwc(dx, B, C, H, W, X.p, X.ld, 0, c.stream));
+                run_conv(c, g, X, Y);
+            } else {
+                run_conv_nchw(c, g, dx, B, H, W, Y);
+            }
+            if (!c.dry) BRN_HIP(launch_nhwc_to_nchw(Y.p, B, O, Ho, Wo, Y.ld, 0, dy, c.stream));
+        });
+        st.finish();
+    });
+}
+
+brn_status brn_upsample_bilinear2d(const float* x, int B, int C, int H, int W, int oh, int ow, float* y, brn_mem loc,
+                                   int device, void* stream) {
+    return guarded([&] {
+        if (!x || !y || B < 1 || C < 1 || H < 1 || W < 1 || oh < 1 || ow < 1) fail(BRN_ERR_INVALID_ARG, "bad argument");
+        ensure_device(device);
+        Staging st(stream, loc);
+        const float* dx = st.in(x, (size_t)B * C * H * W);
+        float* dy = st.out(y, (size_t)B * C * oh * ow);
+        BRN_HIP(launch_resize_nchw(dx, B * C, H, W, dy, oh, ow, (hipStream_t)stream));
+        BRN_HIP(hipStreamSynchronize((hipStream_t)stream));
+        st.finish();
+    });
+}
+
+brn_status brn_window_attention_forward(const float* x, int B, int H, int W, int C, int heads, int window_size, int shift,
+                                        const float* qkv_w, const float* qkv_b, const float* proj_w, const float* proj_b,
+                                        const float* rel_table, float* y, brn_mem loc, int device, void* stream) {
+    return guarded([&] {
+        if (!x || !qkv_w || !qkv_b || !proj_w || !proj_b || !rel_table || !y) fail(BRN_ERR_INVALID_ARG, "null argument");
+        if (window_size != 12 || heads < 1 || C != heads * 32 || !(shift == 0 || shift == 6))
+            fail(BRN_ERR_INVALID_ARG, "window attention needs window_size 12, head_dim 32, shift 0 or 6");
+        ensure_device(device);
+        DeviceOwner own;
+        // reuse the model's weight builder through a one-block table
+        const int T = 23 * 23;
+        int64_t s_qw[2] = {3 * C, C}, s_qb[1] = {3 * C}, s_pw[2] = {C, C}, s_pb[1] = {C}, s_t[2] = {T, heads};
+        SwinBlockW bk;
+        bk.heads = heads;
+        bk.qkv = make_linear(own, qkv_w, qkv_b, 3 * C, C);
+        bk.proj = make_linear(own, proj_w, proj_b, C, C);
+        (void)s_qw; (void)s_qb; (void)s_pw; (void)s_pb; (void)s_t;
+        {
+            const int ws = 12, N = 144;
+            std::vector<float> bt((size_t)heads * N * N);
+            for (int q = 0; q < N; ++q)
+                for (int k = 0; k < N; ++k) {
+                    const int idx = (q / ws - k / ws + ws - 1) * (2 * ws - 1) + (q % ws - k % ws + ws - 1);
+                    for (int h = 0; h < heads; ++h) bt[((size_t)h * N + k) * N + q] = rel_table[(size_t)idx * heads + h];
+                }
+            bk.biasT = own.upload(bt);
+        }
+        Staging st(stream, loc);
+        const float* dx = st.in(x, (size_t)B * H * W * C);
+        float* dy = st.out(y, (size_t)B * H * W * C);
+        with_arena((hipStream_t)stream, [&](Ctx& c) { swin_attention(c, bk, dx, B, H, W, C, shift, dy, nullptr); });
+        st.finish();
+    });
+}
+
+brn_status brn_patch_merging_forward(const float* x, int B, int H, int W, int C, const float* ng, const float* nb,
+                                     const float* rw, float* y, brn_mem loc, int device, void* stream) {
+    return guarded([&] {
+        if (!x || !ng || !nb || !rw || !y || B < 1 || H < 1 || W < 1) fail(BRN_ERR_INVALID_ARG, "bad argument");
+        if (C % 32 || 4 * C > 3072) fail(BRN_ERR_INVALID_ARG, "patch merging width %d unsupported", C);
+        ensure_device(device);
+        DeviceOwner own;
+        LNW ln; ln.C = 4 * C; ln.g = own.upload(ng, 4 * C); ln.b = own.upload(nb, 4 * C);
+        GemmW red = make_linear(own, rw, nullptr, 2 * C, 4 * C);
+        const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, M2 = B * Ho * Wo;
+        Staging st(stream, loc);
+        const float* dx = st.in(x, (size_t)B * H * W * C);
+        float* dy = st.out(y, (size_t)M2 * 2 * C);
+        with_arena((hipStream_t)stream, [&](Ctx& c) {
+            float* pm = c.arena->alloc((size_t)M2 * 4 * C);
+            if (!c.dry) {
+                LayerNormParams p{};
+                p.x = dx; p.y = pm; p.rows = M2; p.C = 4 * C; p.gamma = ln.g; p.beta = ln.b; p.eps = 1e-5f;
+                p.ldy = 4 * C; p.mode = 1; p.H = H; p.W = W; p.Cin = C;
+                BRN_HIP(launch_layernorm(p, c.stream));
+            }
+            run_gemm(c, red, pm, M2, 4 * C, dy, 2 * C, 0);
+        });
+        st.finish();
+    });
+}
+
+brn_status brn_deform_conv2d_forward(const float* x, int B, int C, int H, int W, const float* offset_w, const float* offset_b,
+                                     const float* mod_w, const float* mod_b, const float* w, const float* bias, int O, int k,
+                                     int stride, int pad, int mode, float* y, brn_mem loc, int device, void* stream) {
+    return guarded([&] {
+        if (!x || !offset_w || !offset_b || !mod_w || !mod_b || !w || !y || k < 1 || stride < 1 || pad < 0)
+            fail(BRN_ERR_INVALID_ARG, "bad argument");
+        if (mode == BRN_DEFORM_REFERENCE_CPU) {
+            // deform_conv.rs:95-98: offsets and modulator are computed and discarded; the result is regular_conv(x)
+            brn_status s = brn_conv2d_forward(x, B, C, H, W, w, bias, O, k, k, stride, pad, 1, nullptr, nullptr, nullptr,
+                                              nullptr, 0.f, BRN_ACT_NONE, y, loc, device, stream);
+            if (s != BRN_OK) fail(s, "%s", brn_last_error());
+            return;
+        }
+        if (mode != BRN_DEFORM_DEFORMABLE) fail(BRN_ERR_INVALID_ARG, "unknown deform mode %d", mode);
+        if (C % 32) fail(BRN_ERR_INVALID_ARG, "deformable mode needs in_channels %% 32 == 0 (got %d)", C);
+        const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1, kk = k * k;
+        ensure_device(device);
+        DeviceOwner own;
+        std::vector<float> w3((size_t)3 * kk * C * kk), b3((size_t)3 * kk);
+        memcpy(w3.data(), offset_w, (size_t)2 * kk * C * kk * sizeof(float));
+        memcpy(w3.data() + (size_t)2 * kk * C * kk, mod_w, (size_t)kk * C * kk * sizeof(float));
+        memcpy(b3.data(), offset_b, (size_t)2 * kk * sizeof(float));
+        memcpy(b3.data() + 2 * kk, mod_b, (size_t)kk * sizeof(float));
+        GemmW om = make_conv_nhwc(own, w3.data(), b3.data(), 3 * kk, C, C, k, k, stride, pad, 1);
+        om.mode = GEMM_CONV_NHWC;
+        GemmW reg = make_conv_nhwc(own, w, bias, O, C, C, k, k, stride, pad, 1);
+        reg.mode = GEMM_DEFORM_NHWC;
+        Staging st(stream, loc);
+        const float* dx = st.in(x, (size_t)B * C * H * W);
+        float* dy = st.out(y, (size_t)B * O * Ho * Wo);
+        with_arena((hipStream_t)stream, [&](Ctx& c) {
+            Map X = new_map(c, B, H, W, C), Y = new_map(c, B, Ho, Wo, O);
+            const int ldom = (3 * kk + 3) / 4 * 4;
+            Map OM; OM.B = B; OM.H = Ho; OM.W = Wo; OM.C = 3 * kk; OM.ld = ldom; OM.coff = 0;
+            OM.p = c.arena->alloc((size_t)B * Ho * Wo * ldom);
+            if (!c.dry) BRN_HIP(launch_nchw_to_nhwc(dx, B, C, H, W, X.p, X.ld, 0, c.stream));
+            run_conv(c, om, X, OM);
+            if (!c.dry) BRN_HIP(launch_mod_sigmoid2(OM.p, (size_t)B * Ho * Wo, ldom, 2 * kk, 3 * kk, c.stream));
+            run_conv(c, reg, X, Y, OM.p, ldom, 2 * kk);
+            if (!c.dry) BRN_HIP(launch_nhwc_to_nchw(Y.p, B, O, Ho, Wo, Y.ld, 0, dy, c.stream));
+        });
+        st.finish();
+    });
+}
+
+}  // extern "C"

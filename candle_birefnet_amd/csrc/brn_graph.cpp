@@ -1,0 +1,397 @@
+// brn_graph.cpp — the forward graph: BiRefNet::forward_logits (birefnet.rs:412-461), SwinTransformer::forward
+// (swin.rs:768-797), BiRefNetDecoder::forward (birefnet.rs:278-376), BasicDecBlk/ASPPDeformable (decoder.rs:126-141,
+// aspp.rs:303-333) expressed as launches of the gfx950 kernels on one HIP stream, activations channels-last in an HBM
+// arena, every concatenation written in place into column windows of its consumer's input map.
+#include "brn_host.h"
+#include <cmath>
+#include <cstdio>
+
+namespace brn {
+
+static inline int roundup(int x, int m) { return (x + m - 1) / m * m; }
+
+// ---- arena ----------------------------------------------------------------------------------------------------------
+float* Arena::alloc(size_t nfloats) {
+    const size_t bytes = (nfloats * sizeof(float) + 255) & ~(size_t)255;
+    const size_t off = top;
+    top += bytes;
+    if (top > peak) peak = top;
+    if (dry) return reinterpret_cast<float*>(off);   // never dereferenced in a dry run
+    if (top > cap) fail(BRN_ERR_OOM, "workspace arena overflow: need %zu bytes, have %zu", top, cap);
+    return reinterpret_cast<float*>(base + off);
+}
+
+Map new_map(Ctx& c, int B, int H, int W, int C) {
+    Map m;
+    m.B = B; m.H = H; m.W = W; m.C = C; m.ld = C; m.coff = 0;
+    m.p = c.arena->alloc((size_t)B * H * W * C);
+    return m;
+}
+
+// ---- launch bracket -----------------------------------------------------------------------------------------------
+struct Bracket {
+    Ctx& c; bool on;
+    Bracket(Ctx& c_, int fam, double flop, double bytes) : c(c_), on(c_.profile && !c_.dry) {
+        if (!on) return;
+        auto next = [&]() -> hipEvent_t {
+            if (*c.event_next >= c.event_pool->size()) {
+                hipEvent_t e; BRN_HIP(hipEventCreate(&e)); c.event_pool->push_back(e);
+            }
+            return (*c.event_pool)[(*c.event_next)++];
+        };
+        LaunchRecord r; r.fam = fam; r.flop = flop; r.bytes = bytes; r.e0 = next(); r.e1 = next();
+        BRN_HIP(hipEventRecord(r.e0, c.stream));
+        c.records->push_back(r);
+    }
+    ~Bracket() { if (on) (void)hipEventRecord(c.records->back().e1, c.stream); }
+};
+#define BRN_LAUNCH(expr)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) fail(BRN_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));        \
+    } while (0)
+
+// ---- GEMM-shaped pieces -------------------------------------------------------------------------------------------------
+static void fill_epilogue(GemmParams& p, const GemmW& w) {
+    p.bias = w.bias; p.scale = w.scale; p.shift = w.shift; p.act = w.act;
+}
+
+void run_gemm(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* C, int ldc, int c_coff, const float* R, int ldr,
+              int r_coff, const float* bbias, int bbias_rows) {
+    if (c.dry) return;
+    GemmParams p{};
+    p.A = A; p.W = w.w; p.C = C; p.M = M; p.N = w.N; p.K = w.K; p.mode = GEMM_DENSE; p.lda = lda;
+    fill_epilogue(p, w);
+    p.bbias = bbias; p.bbias_rows = bbias_rows > 0 ? bbias_rows : 1;
+    p.R = R; p.ldr = ldr; p.r_coff = r_coff; p.ldc = ldc; p.c_coff = c_coff;
+    const double flop = 2.0 * M * (double)w.N * w.K;
+    const double bytes = 4.0 * ((double)M * w.K + (double)w.N * w.K + (double)M * w.N * (R ? 2 : 1));
+    Bracket b(c, FAM_GEMM_DENSE, flop, bytes);
+    BRN_LAUNCH(launch_gemm(p, c.stream));
+}
+
+void run_conv(Ctx& c, const GemmW& w, const Map& in, const Map& out, const float* om, int om_ld, int om_mask_off) {
+    const int Hout = (in.H + 2 * w.pad - w.dil * (w.kh - 1) - 1) / w.stride + 1;
+    const int Wout = (in.W + 2 * w.pad - w.dil * (w.kw - 1) - 1) / w.stride + 1;
+    if (out.H != Hout || out.W != Wout || out.B != in.B || out.C != w.N)
+        fail(BRN_ERR_INVALID_ARG, "conv output map [%d,%d,%d,%d] does not match expected [%d,%d,%d,%d]", out.B, out.H, out.W,
+             out.C, in.B, Hout, Wout, w.N);
+    if (in.C > w.Cinp || in.coff + w.Cinp > in.ld)
+        fail(BRN_ERR_INVALID_ARG, "conv input window (C=%d coff=%d ld=%d) cannot supply %d channels", in.C, in.coff, in.ld, w.Cinp);
+    const int M = out.B * Hout * Wout;
+    if (w.mode == GEMM_DENSE) {
+        run_gemm(c, w, in.p + in.coff, M, in.ld, out.p, out.ld, out.coff);
+        return;
+    }
+    if (c.dry) return;
+    GemmParams p{};
+    p.A = in.p; p.W = w.w; p.C = out.p; p.M = M; p.N = w.N; p.K = w.K; p.mode = w.mode;
+    p.lda = in.ld; p.a_coff = in.coff;
+    p.Hin = in.H; p.Win = in.W; p.Cin = w.Cinp; p.kh = w.kh; p.kw = w.kw; p.stride = w.stride; p.pad = w.pad; p.dil = w.dil;
+    p.Hout = Hout; p.Wout = Wout; p.Kreal = w.Kreal;
+    p.om = om; p.om_ld = om_ld; p.om_mask_off = om_mask_off;
+    fill_epilogue(p, w);
+    p.bbias_rows = 1; p.ldc = out.ld; p.c_coff = out.coff;
+    if (w.mode == GEMM_DEFORM_NHWC && !om) fail(BRN_ERR_INVALID_ARG, "deformable conv without an offset/modulator map");
+    const double flop = 2.0 * M * (double)w.N * w.K;
+    const double bytes = 4.0 * ((double)in.pixels() * w.Cinp + (double)w.N * w.K + (double)M * w.N);
+    Bracket b(c, w.mode == GEMM_DEFORM_NHWC ? FAM_GEMM_DEFORM : FAM_GEMM_CONV, flop, bytes);
+    BRN_LAUNCH(launch_gemm(p, c.stream));
+}
+
+void run_conv_nchw(Ctx& c, const GemmW& w, const float* x, int B, int Hin, int Win, const Map& out) {
+    const int Hout = (Hin + 2 * w.pad - w.dil * (w.kh - 1) - 1) / w.stride + 1;
+    const int Wout = (Win + 2 * w.pad - w.dil * (w.kw - 1) - 1) / w.stride + 1;
+    if (out.H != Hout || out.W != Wout || out.B != B || out.C != w.N)
+        fail(BRN_ERR_INVALID_ARG, "conv(nchw) output map mismatch");
+    if (c.dry) return;
+    const int M = B * Hout * Wout;
+    GemmParams p{};
+    p.A = x; p.W = w.w; p.C = out.p; p.M = M; p.N = w.N; p.K = w.K; p.mode = GEMM_GATHER_NCHW;
+    p.Hin = Hin; p.Win = Win; p.Cin = w.Cin; p.kh = w.kh; p.kw = w.kw; p.stride = w.stride; p.pad = w.pad; p.dil = w.dil;
+    p.Hout = Hout; p.Wout = Wout; p.Kreal = w.Kreal;
+    fill_epilogue(p, w);
+    p.bbias_rows = 1; p.ldc = out.ld; p.c_coff = out.coff;
+    const double flop = 2.0 * M * (double)w.N * w.Kreal;
+    const double bytes = 4.0 * ((double)B * w.Cin * Hin * Win + (double)w.N * w.K + (double)M * w.N);
+    Bracket b(c, FAM_GEMM_GATHER, flop, bytes);
+    BRN_LAUNCH(launch_gemm(p, c.stream));
+}
+
+void run_layernorm(Ctx& c, const LNW& ln, const float* x, int rows, int ldx, float* y, int ldy, int y_coff) {
+    if (c.dry) return;
+    LayerNormParams p{};
+    p.x = x; p.y = y; p.rows = rows; p.C = ln.C; p.gamma = ln.g; p.beta = ln.b; p.eps = 1e-5f;
+    p.ldx = ldx; p.ldy = ldy; p.y_coff = y_coff; p.mode = 0;
+    Bracket b(c, FAM_LAYERNORM, 0.0, 8.0 * rows * (double)ln.C);
+    BRN_LAUNCH(launch_layernorm(p, c.stream));
+}
+
+void run_resize(Ctx& c, const Map& in, const Map& out) {
+    if (in.C != out.C || in.B != out.B) fail(BRN_ERR_INVALID_ARG, "resize: channel/batch mismatch");
+    if (c.dry) return;
+    Bracket b(c, FAM_RESIZE, 0.0, 4.0 * ((double)in.pixels() + (double)out.pixels()) * in.C);
+    BRN_LAUNCH(launch_resize_nhwc(in.p, in.B, in.H, in.W, in.C, in.ld, in.coff, out.p, out.H, out.W, out.ld, out.coff, c.stream));
+}
+
+// ---- Swin --------------------------------------------------------------------------------------------------------------
+void swin_stage_dims(int H, int W, int patch, int hs[4], int ws[4]) {
+    int h = (H + patch - 1) / patch, w = (W + patch - 1) / patch;   // PatchEmbed pads to a multiple (swin.rs:696-702)
+    for (int i = 0; i < 4; ++i) {
+        hs[i] = h; ws[i] = w;
+        h = (h + 1) / 2; w = (w + 1) / 2;                            // swin.rs:595
+    }
+}
+
+void swin_attention(Ctx& c, const SwinBlockW& blk, const float* xn, int B, int H, int W, int C, int shift, float* y,
+                    const float* residual) {
+    const size_t mk = c.arena->mark();
+    const int M = B * H * W;
+    float* qkv = c.arena->alloc((size_t)M * 3 * C);
+    float* att = c.arena->alloc((size_t)M * C);
+    run_gemm(c, blk.qkv, xn, M, C, qkv, 3 * C, 0);                   // swin.rs:217 (pad rows are synthesised by the kernel)
+    if (!c.dry) {
+        WindowAttnParams p{};
+        p.qkv = qkv; p.qkv_bias = blk.qkv.bias; p.biasT = blk.biasT; p.out = att;
+        p.B = B; p.H = H; p.W = W; p.C = C; p.heads = blk.heads;
+        p.Hp = roundup(H, 12); p.Wp = roundup(W, 12);                // swin.rs:359-360
+        p.shift = shift; p.scale = 1.0f / sqrtf(32.0f);              // head_dim^-0.5 (swin.rs:134)
+        const double nwin = (double)B * (p.Hp / 12) * (p.Wp / 12) * blk.heads;
+        Bracket b(c, FAM_ATTENTION, nwin * 2.0 * 2.0 * 144 * 144 * 32, 4.0 * ((double)M * 4 * C));
+        BRN_LAUNCH(launch_window_attention(p, c.stream));
+    }
+    run_gemm(c, blk.proj, att, M, C, y, C, 0, residual, C, 0);      // swin.rs:310 (+ shortcut, swin.rs:406)
+    c.arena->release(mk);
+}
+
+void swin_forward(Ctx& c, const SwinW& w, const float* img, int B, int H, int W, const Map outs[4]) {
+    int hs[4], wsz[4];
+    swin_stage_dims(H, W, w.patch, hs, wsz);
+    const size_t mk0 = c.arena->mark();
+    const int E = w.embed_dim;
+    // PatchEmbed (swin.rs:692-714): conv k4 s4 straight from the NCHW image (zero beyond the border = pad_with_zeros), LN
+    float* x = c.arena->alloc((size_t)B * hs[0] * wsz[0] * E);
+    {
+        const size_t mk = c.arena->mark();
+        Map t = new_map(c, B, hs[0], wsz[0], E);
+        run_conv_nchw(c, w.patch_proj, img, B, H, W, t);
+        run_layernorm(c, w.patch_norm, t.p, B * hs[0] * wsz[0], E, x, E, 0);
+        c.arena->release(mk);
+    }
+    for (int i = 0; i < 4; ++i) {
+        const SwinStageW& st = w.stages[i];
+        const int C = st.C, h = hs[i], ww = wsz[i], M = B * h * ww;
+        float* xnext = nullptr;
+        if (st.has_down) xnext = c.arena->alloc((size_t)B * hs[i + 1] * wsz[i + 1] * 2 * C);
+        const size_t mk = c.arena->mark();
+        float* xn = c.arena->alloc((size_t)M * C);
+        const int hidden = st.blocks.empty() ? 4 * C : st.blocks[0].fc1.N;
+        float* hid = c.arena->alloc((size_t)M * hidden);
+        for (size_t j = 0; j < st.blocks.size(); ++j) {
+            const SwinBlockW& bk = st.blocks[j];
+            const int shift = (j % 2 == 0) ? 0 : w.window / 2;                       // swin.rs:552
+            run_layernorm(c, bk.norm1, x, M, C, xn, C, 0);                            // swin.rs:355
+            swin_attention(c, bk, xn, B, h, ww, C, shift, x, x);                      // x = shortcut + attn (swin.rs:406)
+            run_layernorm(c, bk.norm2, x, M, C, xn, C, 0);                            // swin.rs:407
+            run_gemm(c, bk.fc1, xn, M, C, hid, hidden, 0);                            // fc1 + gelu_erf (swin.rs:104-105)
+            run_gemm(c, bk.fc2, hid, M, hidden, x, C, 0, x, C, 0);                    // x + fc2(...) (swin.rs:106,407)
+        }
+        // stage output = norm_i(x_out), pre-downsample (swin.rs:591,784-789); written into its consumer's window
+        if (outs[i].B != B || outs[i].H != h || outs[i].W != ww || outs[i].C != C)
+            fail(BRN_ERR_INVALID_ARG, "swin output window %d has the wrong shape", i);
+        run_layernorm(c, st.out_norm, x, M, C, outs[i].p, outs[i].ld, outs[i].coff);
+        if (st.has_down) {
+            // PatchMerging (swin.rs:491-527): gather 2x2 + LN(4C) fused, then the bias-free reduction
+            const int M2 = B * hs[i + 1] * wsz[i + 1];
+            float* pm = c.arena->alloc((size_t)M2 * 4 * C);
+            if (!c.dry) {
+                LayerNormParams p{};
+                p.x = x; p.y = pm; p.rows = M2; p.C = 4 * C; p.gamma = st.down_norm.g; p.beta = st.down_norm.b; p.eps = 1e-5f;
+                p.ldy = 4 * C; p.y_coff = 0; p.mode = 1; p.H = h; p.W = ww; p.Cin = C;
+                Bracket b(c, FAM_LAYERNORM, 0.0, 8.0 * M2 * 4.0 * C);
+                BRN_LAUNCH(launch_layernorm(p, c.stream));
+            }
+            run_gemm(c, st.reduction, pm, M2, 4 * C, xnext, 2 * C, 0);
+        }
+        c.arena->release(mk);
+        // x of this stage is dead now; xnext lives just above it on the stack.  (Stack discipline keeps both until mk0.)
+        x = xnext;
+    }
+    c.arena->release(mk0);
+}
+
+// ---- BasicDecBlk (decoder.rs:126-141) with ASPPDeformable (aspp.rs:303-333) ------------------------------------------------
+void decblk_forward(Ctx& c, const DecBlkW& w, const Map& in, const Map& out, int deform_mode) {
+    const size_t mk = c.arena->mark();
+    const int B = in.B, H = in.H, W = in.W, M = B * H * W;
+    Map t = new_map(c, B, H, W, 64);
+    run_conv(c, w.conv_in, in, t);                                   // conv_in + bn_in + relu
+    const ASPPW& a = w.aspp;
+    Map cat = new_map(c, B, H, W, 1024);                             // [aspp1 | deform k1 | k3 | k7]; pooled branch -> bias
+    if (deform_mode == BRN_DEFORM_REFERENCE_CPU) {
+        run_gemm(c, a.k1pair, t.p, M, 64, cat.p, 1024, 0);           // aspp1 + aspp_deforms.0 (regular 1x1, BN, ReLU)
+        run_conv(c, a.d[2].regular, t, cat.window(512, 256));        // k3
+        run_conv(c, a.d[3].regular, t, cat.window(768, 256));        // k7
+    } else {
+        for (int i = 0; i < 4; ++i) {
+            const DeformW& d = a.d[i];
+            const int kk = d.k * d.k, ldom = roundup(3 * kk, 4);
+            const size_t mk2 = c.arena->mark();
+            Map om; om.B = B; om.H = H; om.W = W; om.C = 3 * kk; om.ld = ldom; om.coff = 0;
+            om.p = c.arena->alloc((size_t)M * ldom);
+            run_conv(c, d.offmod, t, om);                            // offset_conv | modulator_conv (aspp.rs:171,173)
+            if (!c.dry) {
+                Bracket b(c, FAM_ELEMENTWISE, 0.0, 8.0 * M * kk);
+                BRN_LAUNCH(launch_mod_sigmoid2(om.p, (size_t)M, ldom, 2 * kk, 3 * kk, c.stream));   // 2*sigmoid (aspp.rs:174)
+            }
+            run_conv(c, d.regular, t, cat.window(256 * i, 256), om.p, ldom, 2 * kk);
+            c.arena->release(mk2);
+        }
+    }
+    // pooled branch: mean over H then W (aspp.rs:314), 1x1 conv (no bias) + BN + ReLU, nearest-broadcast (aspp.rs:315-318)
+    float* g0 = c.arena->alloc((size_t)B * 64);
+    float* g1 = c.arena->alloc((size_t)B * 256);
+    float* gb = c.arena->alloc((size_t)B * 64);
+    if (!c.dry) {
+        Bracket b(c, FAM_ELEMENTWISE, 0.0, 4.0 * M * 64);
+        BRN_LAUNCH(launch_gap_nhwc(t.p, B, H * W, 64, 64, 0, g0, c.stream));
+        BRN_LAUNCH(launch_small_fc(g0, B, 64, a.gap_w, 64, 0, 256, a.gap_scale, a.gap_shift, ACT_RELU, g1, c.stream));
+        BRN_LAUNCH(launch_small_fc(g1, B, 256, a.conv1_full, 1280, 1024, 64, nullptr, nullptr, ACT_NONE, gb, c.stream));
+    }
+    Map u = new_map(c, B, H, W, 64);
+    run_gemm(c, a.conv1_main, cat.p, M, 1024, u.p, 64, 0, nullptr, 0, 0, gb, H * W);   // conv1 + bn1 + relu (aspp.rs:329-331)
+    run_conv(c, w.conv_out, u, out);                                 // conv_out + bn_out (no ReLU)
+    c.arena->release(mk);
+}
+
+// ---- decoder (birefnet.rs:278-376) ---------------------------------------------------------------------------------------
+static void ipt_block(Ctx& c, const SimpleConvsW& w, const float* img, int B, int H, int W, int th, int tw, int cin,
+                      const Map& out) {
+    const size_t mk = c.arena->mark();
+    const int cinp = roundup(cin, 32);
+    Map pt = new_map(c, B, th, tw, cinp);
+    if (!c.dry) {
+        Bracket b(c, FAM_ELEMENTWISE, 0.0, 8.0 * B * 3.0 * H * W);
+        BRN_LAUNCH(launch_image2patches(img, B, 3, H, W, th, tw, pt.p, cinp, cinp, c.stream));   // birefnet.rs:288-300
+    }
+    Map mid = new_map(c, B, th, tw, 64);
+    run_conv(c, w.conv1, pt, mid);        // no activation between the two convs (decoder.rs:52)
+    run_conv(c, w.conv_out, mid, out);
+    c.arena->release(mk);
+}
+
+static void gdt_gate(Ctx& c, const DecoderW& d, int i, const Map& p) {
+    const size_t mk = c.arena->mark();
+    Map g = new_map(c, p.B, p.H, p.W, 16);
+    run_conv(c, d.gdt[i], p, g);                                      // conv3x3 -> 16, BN, ReLU (birefnet.rs:111-117)
+    if (!c.dry) {
+        Bracket b(c, FAM_ELEMENTWISE, 0.0, 8.0 * p.pixels() * p.C);
+        BRN_LAUNCH(launch_gdt_gate(p.p, (int)p.pixels(), p.C, p.ld, p.coff, g.p, 16, d.gdt_attn_w[i], d.gdt_attn_b[i], c.stream));
+    }
+    c.arena->release(mk);
+}
+
+void decoder_forward(Ctx& c, const Model& m, const float* img, int B, int H, int W, const Map& x1, const Map& x2, const Map& x3,
+                     const Map& d4, float* out, int apply_sigmoid) {
+    const DecoderW& d = m.dec;
+    const int dm = m.cfg.deform_mode;
+    const int h4 = H / 32, w4 = W / 32, h3 = H / 16, w3 = W / 16, h2 = H / 8, w2 = W / 8, h1 = H / 4, w1 = W / 4;
+    const size_t mk = c.arena->mark();
+    // stage 4: cat(x4, ipt5) -> decoder_block4 -> gate (birefnet.rs:304-305, 323-329)
+    ipt_block(c, d.ipt[4], img, B, H, W, h4, w4, 3072, d4.window(3072, 384));
+    Map p4 = new_map(c, B, h4, w4, 1536);
+    decblk_forward(c, d.dec[0], d4, p4, dm);
+    gdt_gate(c, d, 0, p4);
+    // stage 3 (birefnet.rs:332-344); ipt4_up is a same-size resize = identity
+    Map d3 = new_map(c, B, h3, w3, 1920);
+    run_resize(c, p4, d3.window(0, 1536));
+    run_gemm(c, d.lat[0], x3.p + x3.coff, B * h3 * w3, x3.ld, d3.p, d3.ld, 0, d3.p, d3.ld, 0);   // + lateral_block4(x3)
+    ipt_block(c, d.ipt[3], img, B, H, W, h3, w3, 768, d3.window(1536, 384));
+    Map p3 = new_map(c, B, h3, w3, 768);
+    decblk_forward(c, d.dec[1], d3, p3, dm);
+    gdt_gate(c, d, 1, p3);
+    // stage 2 (birefnet.rs:347-359)
+    Map d2 = new_map(c, B, h2, w2, 960);
+    run_resize(c, p3, d2.window(0, 768));
+    run_gemm(c, d.lat[1], x2.p + x2.coff, B * h2 * w2, x2.ld, d2.p, d2.ld, 0, d2.p, d2.ld, 0);
+    ipt_block(c, d.ipt[2], img, B, H, W, h2, w2, 192, d2.window(768, 192));
+    Map p2 = new_map(c, B, h2, w2, 384);
+    decblk_forward(c, d.dec[2], d2, p2, dm);
+    gdt_gate(c, d, 2, p2);
+    // stage 1 (birefnet.rs:362-369)
+    Map d1 = new_map(c, B, h1, w1, 480);
+    run_resize(c, p2, d1.window(0, 384));
+    run_gemm(c, d.lat[2], x1.p + x1.coff, B * h1 * w1, x1.ld, d1.p, d1.ld, 0, d1.p, d1.ld, 0);
+    ipt_block(c, d.ipt[1], img, B, H, W, h1, w1, 48, d1.window(384, 96));
+    Map p1 = new_map(c, B, h1, w1, 192);
+    decblk_forward(c, d.dec[3], d1, p1, dm);
+    // head (birefnet.rs:372-375): q = <p1, w[0:192]> at 1/4 res; t = composed 3x3 stencil over ipt_blk1.conv1(x)
+    float* q = c.arena->alloc((size_t)B * h1 * w1);
+    float* tl = c.arena->alloc((size_t)B * H * W);
+    Map u = new_map(c, B, H, W, 64);
+    run_conv_nchw(c, d.ipt[0].conv1, img, B, H, W, u);
+    if (!c.dry) {
+        Bracket b(c, FAM_ELEMENTWISE, 2.0 * B * H * (double)W * 576, 4.0 * B * H * (double)W * 65);
+        BRN_LAUNCH(launch_pixel_dot(p1.p, B * h1 * w1, 192, p1.ld, p1.coff, d.out_w, 0.f, q, c.stream));
+        BRN_LAUNCH(launch_conv3x3_to1(u.p, B, H, W, 64, 64, d.tail_w, d.tail_b, tl, c.stream));
+        BRN_LAUNCH(launch_final_head(q, B, h1, w1, tl, d.out_b, H, W, apply_sigmoid, out, c.stream));
+    }
+    c.arena->release(mk);
+}
+
+// ---- BiRefNet::forward_logits (birefnet.rs:412-461) ----------------------------------------------------------------------------
+void model_forward(Model& m, Ctx& c, const float* img, int B, int H, int W, float* out, int apply_sigmoid) {
+    if (H % 32 || W % 32 || H < 32 || W < 32)
+        fail(BRN_ERR_INVALID_ARG, "input %dx%d: H and W must be positive multiples of 32 (image2patches, birefnet.rs:288-300)", H, W);
+    const bool prof = c.profile && !c.dry && m.stage_ev_ok;
+    auto stamp = [&](int i) { if (prof) BRN_HIP(hipEventRecord(m.stage_ev[i], c.stream)); };
+    const size_t mk = c.arena->mark();
+    const int h1 = H / 4, w1 = W / 4, h2 = H / 8, w2 = W / 8, h3 = H / 16, w3 = W / 16, h4 = H / 32, w4 = W / 32;
+    // multi-scale concat targets (birefnet.rs:440-443) and the context concat (birefnet.rs:453): [x1|x2|x3|x4] at 1/32
+    Map X1 = new_map(c, B, h1, w1, 384), X2 = new_map(c, B, h2, w2, 768), X3 = new_map(c, B, h3, w3, 1536);
+    Map X4 = new_map(c, B, h4, w4, 5760);
+    stamp(0);
+    {
+        Map outs[4] = {X1.window(0, 192), X2.window(0, 384), X3.window(0, 768), X4.window(2688, 1536)};
+        swin_forward(c, m.swin, img, B, H, W, outs);                                  // birefnet.rs:416
+    }
+    stamp(1);
+    {
+        const size_t mk2 = c.arena->mark();
+        const int Hh = H / 2, Wh = W / 2;
+        float* half = c.arena->alloc((size_t)B * 3 * Hh * Wh);
+        if (!c.dry) {
+            Bracket b(c, FAM_RESIZE, 0.0, 4.0 * B * 3.0 * (H * (double)W + Hh * (double)Wh));
+            BRN_LAUNCH(launch_resize_nchw(img, B * 3, H, W, half, Hh, Wh, c.stream));  // birefnet.rs:425
+        }
+        int hs[4], ws[4];
+        swin_stage_dims(Hh, Wh, m.swin.patch, hs, ws);
+        Map hm[4];
+        for (int i = 0; i < 4; ++i) hm[i] = new_map(c, B, hs[i], ws[i], 192 << i);
+        swin_forward(c, m.swin, half, B, Hh, Wh, hm);                                 // birefnet.rs:426
+        run_resize(c, hm[0], X1.window(192, 192));                                    // birefnet.rs:435-443
+        run_resize(c, hm[1], X2.window(384, 384));
+        run_resize(c, hm[2], X3.window(768, 768));
+        run_resize(c, hm[3], X4.window(4224, 1536));
+        c.arena->release(mk2);
+        // context: x1, x2, x3 bilinearly DOWN-sampled to 1/32 (no antialias), birefnet.rs:450-453
+        run_resize(c, X1, X4.window(0, 384));
+        run_resize(c, X2, X4.window(384, 768));
+        run_resize(c, X3, X4.window(1152, 1536));
+    }
+    stamp(2);
+    Map D4 = new_map(c, B, h4, w4, 3456);
+    decblk_forward(c, m.squeeze, X4, D4.window(0, 3072), m.cfg.deform_mode);          // birefnet.rs:457
+    stamp(3);
+    decoder_forward(c, m, img, B, H, W, X1, X2, X3, D4, out, apply_sigmoid);          // birefnet.rs:460
+    stamp(4);
+    c.arena->release(mk);
+}
+
+Model::~Model() {
+    if (arena.base) (void)hipFree(arena.base);
+    for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
+    if (stage_ev_ok) for (int i = 0; i < 6; ++i) (void)hipEventDestroy(stage_ev[i]);
+}
+
+}  // namespace brn

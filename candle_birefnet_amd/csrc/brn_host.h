@@ -1,0 +1,192 @@
+// brn_host.h — host-side runtime of libbirefnet_hip.so: error plumbing, HBM arena, prepared weights, the model graph.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <string>
+#include <vector>
+#include <unordered_map>
+#include <stdexcept>
+#include <mutex>
+#include "../../include/birefnet_hip.h"
+#include "brn_kernels.h"
+
+namespace brn {
+
+// ---- errors: C++ exceptions inside, status codes at the ABI ------------------------------------------------
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+[[noreturn]] void fail(int code, const char* fmt, ...);
+void set_last_error(const std::string& s);
+#define BRN_HIP(call)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess) ::brn::fail(BRN_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// ---- kernel families for the per-launch accounting (brn_model_last_kernel_stats) --------------------------
+enum Family {
+    FAM_GEMM_DENSE = 0, FAM_GEMM_CONV, FAM_GEMM_GATHER, FAM_GEMM_DEFORM, FAM_ATTENTION, FAM_LAYERNORM,
+    FAM_RESIZE, FAM_ELEMENTWISE, FAM_COUNT
+};
+
+struct LaunchRecord { int fam; double flop; double bytes; hipEvent_t e0, e1; };
+
+// ---- HBM arena: one allocation, stack discipline (mark / release) ------------------------------------------
+// In dry-run mode nothing is allocated or launched: the same graph code walks the plan and records the peak.
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, top = 0, peak = 0;
+    bool dry = false;
+    float* alloc(size_t nfloats);
+    size_t mark() const { return top; }
+    void release(size_t m) { top = m; }
+};
+
+struct Ctx {
+    Arena* arena;
+    hipStream_t stream;
+    bool dry;                       // plan only
+    bool profile;                   // bracket every launch with events
+    std::vector<LaunchRecord>* records;
+    std::vector<hipEvent_t>* event_pool; size_t* event_next;
+};
+
+// channels-last window view: logical [B,H,W,C] living in columns [coff, coff+C) of rows that are ld floats wide
+struct Map {
+    float* p = nullptr;
+    int B = 0, H = 0, W = 0, C = 0, ld = 0, coff = 0;
+    size_t pixels() const { return (size_t)B * H * W; }
+    Map window(int c0, int c) const { Map m = *this; m.coff = coff + c0; m.C = c; return m; }
+};
+Map new_map(Ctx& c, int B, int H, int W, int C);
+
+// ---- prepared weights ---------------------------------------------------------------------------------------
+struct DevVec { float* p = nullptr; size_t n = 0; };
+
+struct GemmW {          // one Linear / Conv2d, repacked for gemm_f32
+    float* w = nullptr; // [roundup(N,128)][K]
+    int N = 0, K = 0, Kreal = 0;
+    int Cin = 0, Cinp = 0, kh = 1, kw = 1, stride = 1, pad = 0, dil = 1;
+    int mode = GEMM_DENSE;
+    float* bias = nullptr;   // [N] or null
+    float* scale = nullptr;  // folded eval-BN (with the conv bias folded into shift) or null
+    float* shift = nullptr;
+    int act = ACT_NONE;
+};
+struct LNW { float* g = nullptr; float* b = nullptr; int C = 0; };
+
+struct SwinBlockW {
+    LNW norm1, norm2;
+    GemmW qkv, proj, fc1, fc2;
+    float* biasT = nullptr;   // [heads][144][144]
+    int heads = 0;
+};
+struct SwinStageW {
+    std::vector<SwinBlockW> blocks;
+    bool has_down = false;
+    LNW down_norm; GemmW reduction;
+    LNW out_norm;
+    int C = 0, heads = 0;
+};
+struct SwinW {
+    GemmW patch_proj; LNW patch_norm;
+    SwinStageW stages[4];
+    int embed_dim = 0, window = 12, patch = 4, in_ch = 3;
+};
+struct DeformW {           // DeformConvASPP (aspp.rs:13-56)
+    int k = 1;
+    GemmW offmod;          // offset_conv and modulator_conv stacked on N: [2k^2 | k^2] (deformable mode only)
+    GemmW regular;         // regular_conv + the ASPP module's BN + ReLU folded (aspp.rs:217-222)
+};
+struct ASPPW {             // ASPPDeformable (aspp.rs:227-333)
+    GemmW k1pair;          // reference_cpu mode: aspp1 and aspp_deforms.0 (both 1x1) stacked on N = 512
+    DeformW d[4];          // aspp1, deform k1, k3, k7
+    float* gap_w = nullptr; float* gap_scale = nullptr; float* gap_shift = nullptr;   // global_avg_pool.1/.2
+    float* conv1_full = nullptr;   // [64][1280] (for the pooled branch's contribution)
+    GemmW conv1_main;      // [64][1024] + bn1 + relu
+};
+struct DecBlkW { GemmW conv_in; ASPPW aspp; GemmW conv_out; int cin = 0, cout = 0; };
+struct SimpleConvsW { GemmW conv1, conv_out; };
+struct DecoderW {
+    SimpleConvsW ipt[5];   // ipt_blk1..5 (ipt[0] = ipt_blk1: conv1 only, conv_out is composed into tail_w)
+    float* tail_w = nullptr; float tail_b = 0.f;   // [9][64]: conv_out1[192:240] o ipt_blk1.conv_out
+    DecBlkW dec[4];        // decoder_block4,3,2,1
+    GemmW lat[3];          // lateral_block4,3,2
+    GemmW gdt[3];          // gdt_convs_4,3,2 (conv + BN + ReLU)
+    float* gdt_attn_w[3] = {nullptr, nullptr, nullptr}; float gdt_attn_b[3] = {0, 0, 0};
+    float* out_w = nullptr; float out_b = 0.f;     // conv_out1.0 weight [240] (first 192 used by pixel_dot)
+};
+
+struct WeightTable {
+    std::unordered_map<std::string, const brn_named_tensor*> map;
+    WeightTable(const brn_named_tensor* w, size_t n);
+    const brn_named_tensor* get(const std::string& name, std::initializer_list<int64_t> shape) const;
+};
+
+struct DeviceOwner {     // every hipMalloc of a model, freed together
+    std::vector<void*> ptrs;
+    float* upload(const float* host, size_t n);
+    float* upload(const std::vector<float>& v) { return upload(v.data(), v.size()); }
+    ~DeviceOwner();
+};
+
+// ---- model ---------------------------------------------------------------------------------------------------
+struct Model {
+    brn_config cfg;
+    int device = 0;
+    DeviceOwner own;
+    SwinW swin;
+    DecBlkW squeeze;
+    DecoderW dec;
+    bool has_decoder = false;
+    Arena arena;
+    int plan_B = 0, plan_H = 0, plan_W = 0;
+    std::mutex mu;            // forward calls on one handle are serialised (one workspace)
+    bool profiling = false;
+    std::vector<LaunchRecord> records;
+    std::vector<hipEvent_t> event_pool; size_t event_next = 0;
+    hipEvent_t stage_ev[6]; bool stage_ev_ok = false;
+    float last_ms[5] = {0, 0, 0, 0, 0};
+    int fam_launches[FAM_COUNT]; float fam_ms[FAM_COUNT]; double fam_flop[FAM_COUNT]; double fam_bytes[FAM_COUNT];
+    ~Model();
+};
+
+void build_swin_weights(const WeightTable& wt, const std::string& prefix, const brn_config& cfg, DeviceOwner& own, SwinW& out);
+void build_decblk_weights(const WeightTable& wt, const std::string& prefix, int cin, int cout, int deform_mode, DeviceOwner& own, DecBlkW& out);
+void build_decoder_weights(const WeightTable& wt, const std::string& prefix, const brn_config& cfg, DeviceOwner& own, DecoderW& out);
+
+// generic weight repack helpers (also used by the op-level entry points)
+GemmW make_linear(DeviceOwner& own, const float* w, const float* bias, int N, int K);
+// conv for a channels-last input whose channel count is cin_padded (>= Cin, % 32 == 0); NHWC K order
+GemmW make_conv_nhwc(DeviceOwner& own, const float* w, const float* bias, int O, int Cin, int cin_padded, int kh, int kw,
+                     int stride, int pad, int dil);
+// conv that gathers straight from an NCHW tensor; candle K order
+GemmW make_conv_gather(DeviceOwner& own, const float* w, const float* bias, int O, int Cin, int kh, int kw, int stride, int pad, int dil);
+void fold_bn(DeviceOwner& own, GemmW& g, const float* conv_bias_host, const float* gamma, const float* beta,
+             const float* mean, const float* var, float eps);
+
+// ---- graph pieces ------------------------------------------------------------------------------------------------
+void run_gemm(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* C, int ldc, int c_coff,
+              const float* R = nullptr, int ldr = 0, int r_coff = 0, const float* bbias = nullptr, int bbias_rows = 1);
+void run_conv(Ctx& c, const GemmW& w, const Map& in, const Map& out, const float* om = nullptr, int om_ld = 0, int om_mask_off = 0);
+void run_conv_nchw(Ctx& c, const GemmW& w, const float* x_nchw, int B, int Hin, int Win, const Map& out);
+void run_layernorm(Ctx& c, const LNW& ln, const float* x, int rows, int ldx, float* y, int ldy, int y_coff);
+void run_resize(Ctx& c, const Map& in, const Map& out);
+
+// SwinTransformer::forward (swin.rs:768-797): outs[i] are destination windows (stage outputs after norm_i)
+void swin_forward(Ctx& c, const SwinW& w, const float* img_nchw, int B, int H, int W, const Map outs[4]);
+void swin_stage_dims(int H, int W, int patch, int hs[4], int ws[4]);
+// the attention half of one block (swin.rs:356-403), x is the norm1 output, y = proj(attn) (no residual) or += residual
+void swin_attention(Ctx& c, const SwinBlockW& blk, const float* xn, int B, int H, int W, int C, int shift,
+                    float* y, const float* residual);
+void decblk_forward(Ctx& c, const DecBlkW& w, const Map& in, const Map& out, int deform_mode);
+void decoder_forward(Ctx& c, const Model& m, const float* img_nchw, int B, int H, int W, const Map& x1, const Map& x2,
+                     const Map& x3, const Map& d4 /* [.., 3456] with [0:3072) = squeezed x4 */, float* out, int apply_sigmoid);
+void model_forward(Model& m, Ctx& c, const float* img_nchw, int B, int H, int W, float* out, int apply_sigmoid);
+
+void ensure_device(int ordinal);
+
+}  // namespace brn

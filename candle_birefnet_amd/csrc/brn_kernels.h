@@ -1,0 +1,104 @@
+// brn_kernels.h — internal launch interface of the gfx950 kernels (not part of the C ABI).
+// All activations are fp32, channels-last: a "map" is [B, H, W, ld] with the logical channels living in a
+// column window [coff, coff+C) of the ld-wide rows, so concatenations are written in place (no cat copies).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace brn {
+
+enum GemmMode {
+    GEMM_DENSE = 0,       // A[m][k] = A + m*lda + k                         (Linear layers, 1x1 convs)
+    GEMM_CONV_NHWC = 1,   // implicit im2col over a channels-last map, K = (ky,kx,ci), Cin % 32 == 0
+    GEMM_GATHER_NCHW = 2, // implicit im2col over an NCHW image, K = (ci,ky,kx) (candle weight order), any Cin
+    GEMM_DEFORM_NHWC = 3  // modulated deformable im2col (bilinear gather * mask), K = (ky,kx,ci), Cin % 32 == 0
+};
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU_ERF = 2 };
+
+struct GemmParams {
+    const float* A;
+    const float* W;       // [Npad][K] row-major, K contiguous, rows >= roundup(N, 128), K % 32 == 0, zero padded
+    float* C;
+    int M, N, K;
+    int mode;
+    int lda;              // dense: row stride; conv/deform: floats per pixel of the input map
+    int a_coff;           // conv/deform: first channel of the input window
+    // conv geometry (modes 1..3)
+    int Hin, Win, Cin, kh, kw, stride, pad, dil, Hout, Wout;
+    int Kreal;            // mode 2: Cin*kh*kw before padding to 32
+    // deformable (mode 3): om = [B,Hout,Wout,om_ld] holding 2*kh*kw offsets (dy,dx interleaved, torchvision
+    // order) then kh*kw modulator logits (already 2*sigmoid applied) starting at column om_mask_off
+    const float* om; int om_ld; int om_mask_off;
+    // epilogue:  v = acc (+ bias[n]) (+ bbias[m / bbias_rows][n]);  v = v*scale[n] + shift[n];  v = act(v);
+    //            v += R[m*ldr + r_coff + n];  C[m*ldc + c_coff + n] = v
+    const float* bias;
+    const float* bbias; int bbias_rows;
+    const float* scale; const float* shift;
+    int act;
+    const float* R; int ldr; int r_coff;
+    int ldc; int c_coff;
+};
+
+// returns hipError_t of the launch
+hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
+
+struct LayerNormParams {
+    const float* x; float* y;
+    int rows, C;
+    const float* gamma; const float* beta; float eps;
+    int ldx;              // input row stride (mode 0)
+    int ldy, y_coff;      // output row stride / column offset
+    // mode 1: PatchMerging gather (swin.rs:505-522): row (b,i,j) of the merged map gathers the four tokens
+    // (2i,2j),(2i+1,2j),(2i,2j+1),(2i+1,2j+1) of x [B,H,W,Cin], zero outside (odd H/W padding), C == 4*Cin
+    int mode; int H, W, Cin;
+};
+hipError_t launch_layernorm(const LayerNormParams& p, hipStream_t s);
+
+struct WindowAttnParams {
+    const float* qkv;     // [B, H, W, 3C] natural token order (q | k | v, heads-major inside each, swin.rs:218)
+    const float* qkv_bias;// [3C]  (q/k/v of a zero pad token)
+    const float* biasT;   // [heads][N key][N query] relative position bias, transposed cached_bias (swin.rs:147-152)
+    float* out;           // [B, H, W, C]
+    int B, H, W, C, heads;
+    int Hp, Wp;           // padded canvas (multiples of 12)
+    int shift;            // 0 or 6
+    float scale;          // head_dim^-0.5
+};
+hipError_t launch_window_attention(const WindowAttnParams& p, hipStream_t s);
+
+// ---- data movement / elementwise (HBM-bound) ------------------------------------------------------------
+// bilinear, align_corners=true, channels-last window -> window; optional accumulate (y += )
+hipError_t launch_resize_nhwc(const float* x, int B, int Hin, int Win, int C, int ldx, int x_coff,
+                              float* y, int Hout, int Wout, int ldy, int y_coff, hipStream_t s);
+// NCHW planar bilinear (the 3-channel image -> half scale), align_corners=true
+hipError_t launch_resize_nchw(const float* x, int BC, int Hin, int Win, float* y, int Hout, int Wout, hipStream_t s);
+// NCHW -> NHWC window and back
+hipError_t launch_nchw_to_nhwc(const float* x, int B, int C, int H, int W, float* y, int ldy, int y_coff, hipStream_t s);
+hipError_t launch_nhwc_to_nchw(const float* x, int B, int C, int H, int W, int ldx, int x_coff, float* y, hipStream_t s);
+// image2patches (birefnet.rs:288-300): x NCHW [B,Cimg,H,W] -> y[b, th, tw, (c,gh,gw)] channels-last, ld = ldy
+hipError_t launch_image2patches(const float* x, int B, int Cimg, int H, int W, int th, int tw,
+                                float* y, int ldy, int cpad, hipStream_t s);
+// per-(b,c) mean over H*W of a channels-last window: out[b][c]   (aspp.rs:314)
+hipError_t launch_gap_nhwc(const float* x, int B, int HW, int C, int ldx, int x_coff, float* out, hipStream_t s);
+// tiny dense layers on [B,Cin] vectors: y[b][n] = act((sum_k x[b][k] w[n*ldw + w_off + k]) * scale[n] + shift[n])
+hipError_t launch_small_fc(const float* x, int B, int Cin, const float* w, int ldw, int w_off, int N,
+                           const float* scale, const float* shift, int act, float* y, hipStream_t s);
+// GDT gate (birefnet.rs:327-329): a = sigmoid(dot(g[pix][0:16], w) + b); p[pix][0:C] *= a
+hipError_t launch_gdt_gate(float* p, int npix, int C, int ldp, int p_coff, const float* g, int ldg,
+                           const float* w, float bias, hipStream_t s);
+// per-pixel dot: y[pix] = dot(x[pix][0:C], w) (+ bias)
+hipError_t launch_pixel_dot(const float* x, int npix, int C, int ldx, int x_coff, const float* w, float bias,
+                            float* y, hipStream_t s);
+// final head (birefnet.rs:372-375 with conv_out1 commuted through the bilinear upsample):
+// out[b][oy][ox] = bilinear(q [B,h,w] -> H,W) + t[b][oy][ox] (+bias); optional sigmoid
+hipError_t launch_final_head(const float* q, int B, int h, int w, const float* t, float bias, int H, int W,
+                             int apply_sigmoid, float* out, hipStream_t s);
+// 3x3 conv, pad 1, of a 64-channel channels-last map to one channel (composed ipt_blk1.conv_out o conv_out1 slice)
+hipError_t launch_conv3x3_to1(const float* x, int B, int H, int W, int C, int ldx, const float* w, float bias,
+                              float* y, hipStream_t s);
+// y = sigmoid(x)
+hipError_t launch_sigmoid(const float* x, size_t n, float* y, hipStream_t s);
+// modulator epilogue for deformable mode: columns [c0,c1) of rows get 2/(1+exp(-x))   (aspp.rs:173-174)
+hipError_t launch_mod_sigmoid2(float* x, size_t rows, int ld, int c0, int c1, hipStream_t s);
+
+} // namespace brn

@@ -1,0 +1,379 @@
+// brn_weights.cpp — BiRefNet::new (birefnet.rs:389-409) on the device side: look the tensors up by their
+// VarBuilder names, repack them for gemm_f32 (K-contiguous, channels-last tap order, rows padded
+// to the tile), fold eval-mode BatchNorm into per-channel scale/shift, precompute the transposed relative-position
+// bias per block (the analogue of WindowAttention::cached_bias, swin.rs:147-152), upload once.
+#include "brn_host.h"
+#include <cmath>
+#include <cstring>
+#include <cstdio>
+
+namespace brn {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& s) { g_last_error = s; }
+const char* last_error_cstr() { return g_last_error.c_str(); }
+
+void fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    throw Error(code, buf);
+}
+
+void ensure_device(int ordinal) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) fail(BRN_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU fallback",
+                                        e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (ordinal < 0 || ordinal >= n) fail(BRN_ERR_NO_DEVICE, "device ordinal %d out of range (have %d)", ordinal, n);
+    BRN_HIP(hipSetDevice(ordinal));
+}
+
+// ---- device ownership -----------------------------------------------------------------------------------------
+float* DeviceOwner::upload(const float* host, size_t n) {
+    void* d = nullptr;
+    hipError_t e = hipMalloc(&d, n * sizeof(float) + 16);
+    if (e != hipSuccess) fail(BRN_ERR_OOM, "hipMalloc of %zu bytes failed: %s", n * sizeof(float), hipGetErrorString(e));
+    ptrs.push_back(d);
+    BRN_HIP(hipMemcpy(d, host, n * sizeof(float), hipMemcpyHostToDevice));
+    return (float*)d;
+}
+DeviceOwner::~DeviceOwner() {
+    for (void* p : ptrs) (void)hipFree(p);
+}
+
+// ---- weight table -----------------------------------------------------------------------------------------------
+WeightTable::WeightTable(const brn_named_tensor* w, size_t n) {
+    for (size_t i = 0; i < n; ++i)
+        if (w[i].name) map[w[i].name] = &w[i];
+}
+const brn_named_tensor* WeightTable::get(const std::string& name, std::initializer_list<int64_t> shape) const {
+    auto it = map.find(name);
+    if (it == map.end()) fail(BRN_ERR_MISSING_TENSOR, "cannot find tensor %s", name.c_str());
+    const brn_named_tensor* t = it->second;
+    bool ok = t->ndim == (int)shape.size() && t->data != nullptr;
+    if (ok) {
+        int i = 0;
+        for (int64_t d : shape) ok = ok && t->shape[i++] == d;
+    }
+    if (!ok) {
+        std::string want, got;
+        for (int64_t d : shape) want += std::to_string(d) + ",";
+        for (int i = 0; i < t->ndim; ++i) got += std::to_string(t->shape[i]) + ",";
+        fail(BRN_ERR_SHAPE, "shape mismatch for %s: expected [%s] got [%s]", name.c_str(), want.c_str(), got.c_str());
+    }
+    return t;
+}
+
+static inline int roundup(int x, int m) { return (x + m - 1) / m * m; }
+
+// ---- repack helpers ------------------------------------------------------------------------------------------------
+GemmW make_linear(DeviceOwner& own, const float* w, const float* bias, int N, int K) {
+    if (K % 32) fail(BRN_ERR_INVALID_ARG, "linear in_features %d must be a multiple of 32", K);
+    GemmW g;
+    g.N = N; g.K = K; g.Kreal = K; g.Cin = K; g.Cinp = K; g.mode = GEMM_DENSE;
+    std::vector<float> pk((size_t)roundup(N, 128) * K, 0.f);
+    memcpy(pk.data(), w, (size_t)N * K * sizeof(float));
+    g.w = own.upload(pk);
+    if (bias) g.bias = own.upload(bias, N);
+    return g;
+}
+
+GemmW make_conv_nhwc(DeviceOwner& own, const float* w, const float* bias, int O, int Cin, int cinp, int kh, int kw,
+                     int stride, int pad, int dil) {
+    if (cinp % 32 || cinp < Cin) fail(BRN_ERR_INVALID_ARG, "padded channel count %d invalid for Cin %d", cinp, Cin);
+    GemmW g;
+    g.N = O; g.K = kh * kw * cinp; g.Kreal = kh * kw * Cin; g.Cin = Cin; g.Cinp = cinp;
+    g.kh = kh; g.kw = kw; g.stride = stride; g.pad = pad; g.dil = dil;
+    g.mode = (kh == 1 && kw == 1 && stride == 1 && pad == 0) ? GEMM_DENSE : GEMM_CONV_NHWC;
+    std::vector<float> pk((size_t)roundup(O, 128) * g.K, 0.f);
+    for (int o = 0; o < O; ++o)
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int ky = 0; ky < kh; ++ky)
+                for (int kx = 0; kx < kw; ++kx)
+                    pk[(size_t)o * g.K + (size_t)(ky * kw + kx) * cinp + ci] = w[(((size_t)o * Cin + ci) * kh + ky) * kw + kx];
+    g.w = own.upload(pk);
+    if (bias) g.bias = own.upload(bias, O);
+    return g;
+}
+
+GemmW make_conv_gather(DeviceOwner& own, const float* w, const float* bias, int O, int Cin, int kh, int kw, int stride,
+                       int pad, int dil) {
+    GemmW g;
+    g.N = O; g.Kreal = Cin * kh * kw; g.K = roundup(g.Kreal, 32); g.Cin = Cin; g.Cinp = Cin;
+    g.kh = kh; g.kw = kw; g.stride = stride; g.pad = pad; g.dil = dil; g.mode = GEMM_GATHER_NCHW;
+    std::vector<float> pk((size_t)roundup(O, 128) * g.K, 0.f);
+    for (int o = 0; o < O; ++o) memcpy(&pk[(size_t)o * g.K], &w[(size_t)o * g.Kreal], (size_t)g.Kreal * sizeof(float));
+    g.w = own.upload(pk);
+    if (bias) g.bias = own.upload(bias, O);
+    return g;
+}
+
+// eval-mode batch_norm after a conv (decoder.rs:128-129): y = ((acc + b) - mean) / sqrt(var + eps) * gamma + beta
+//                                                        = acc * scale + shift
+void fold_bn(DeviceOwner& own, GemmW& g, const float* conv_bias, const float* gamma, const float* beta,
+             const float* mean, const float* var, float eps) {
+    std::vector<float> sc(g.N), sh(g.N);
+    for (int n = 0; n < g.N; ++n) {
+        const double s = (double)gamma[n] / std::sqrt((double)var[n] + (double)eps);
+        const double b = conv_bias ? (double)conv_bias[n] : 0.0;
+        sc[n] = (float)s;
+        sh[n] = (float)((b - (double)mean[n]) * s + (double)beta[n]);
+    }
+    g.scale = own.upload(sc);
+    g.shift = own.upload(sh);
+    g.bias = nullptr;
+}
+
+struct BNHost { const float *g, *b, *m, *v; };
+static BNHost get_bn(const WeightTable& wt, const std::string& p, int C) {
+    BNHost h;
+    h.g = wt.get(p + ".weight", {C})->data;
+    h.b = wt.get(p + ".bias", {C})->data;
+    h.m = wt.get(p + ".running_mean", {C})->data;
+    h.v = wt.get(p + ".running_var", {C})->data;
+    return h;
+}
+static LNW get_ln(const WeightTable& wt, const std::string& p, int C, DeviceOwner& own) {
+    LNW l;
+    l.C = C;
+    l.g = own.upload(wt.get(p + ".weight", {C})->data, C);
+    l.b = own.upload(wt.get(p + ".bias", {C})->data, C);
+    return l;
+}
+static GemmW get_linear(const WeightTable& wt, const std::string& p, int N, int K, bool bias, DeviceOwner& own) {
+    const float* w = wt.get(p + ".weight", {N, K})->data;
+    const float* b = bias ? wt.get(p + ".bias", {N})->data : nullptr;
+    return make_linear(own, w, b, N, K);
+}
+
+// ---- Swin (swin.rs:725-764) -----------------------------------------------------------------------------------------
+void build_swin_weights(const WeightTable& wt, const std::string& pre, const brn_config& cfg, DeviceOwner& own, SwinW& out) {
+    if (cfg.window_size != 12) fail(BRN_ERR_INVALID_ARG, "window_size %d unsupported: the attention kernel is built for 12 (Swin-B/L, swin.rs:60,74)", cfg.window_size);
+    if (cfg.patch_size < 1 || cfg.in_channels < 1) fail(BRN_ERR_INVALID_ARG, "bad patch_size/in_channels");
+    out.embed_dim = cfg.embed_dim; out.window = cfg.window_size; out.patch = cfg.patch_size; out.in_ch = cfg.in_channels;
+    const int E = cfg.embed_dim, P = cfg.patch_size, IC = cfg.in_channels;
+    if (E % 32) fail(BRN_ERR_INVALID_ARG, "embed_dim %d must be a multiple of 32", E);
+    {
+        const float* w = wt.get(pre + "patch_embed.proj.weight", {E, IC, P, P})->data;
+        const float* b = wt.get(pre + "patch_embed.proj.bias", {E})->data;
+        out.patch_proj = make_conv_gather(own, w, b, E, IC, P, P, P, 0, 1);
+        out.patch_norm = get_ln(wt, pre + "patch_embed.norm", E, own);
+    }
+    const int ws = cfg.window_size, N = ws * ws, T = (2 * ws - 1) * (2 * ws - 1);
+    for (int i = 0; i < 4; ++i) {
+        SwinStageW& st = out.stages[i];
+        const int C = E << i, heads = cfg.num_heads[i];
+        st.C = C; st.heads = heads;
+        if (heads <= 0 || C != heads * 32)
+            fail(BRN_ERR_INVALID_ARG, "stage %d: dim %d / heads %d: head_dim must be 32 (Swin-L geometry)", i, C, heads);
+        const int hidden = (int)((double)C * (double)cfg.mlp_ratio);   // swin.rs:337
+        const std::string lp = pre + "layers." + std::to_string(i) + ".";
+        st.blocks.resize(cfg.depths[i]);
+        for (int j = 0; j < cfg.depths[i]; ++j) {
+            SwinBlockW& bk = st.blocks[j];
+            const std::string bp = lp + "blocks." + std::to_string(j) + ".";
+            bk.heads = heads;
+            bk.norm1 = get_ln(wt, bp + "norm1", C, own);
+            bk.norm2 = get_ln(wt, bp + "norm2", C, own);
+            bk.qkv = get_linear(wt, bp + "attn.qkv", 3 * C, C, true, own);
+            bk.proj = get_linear(wt, bp + "attn.proj", C, C, true, own);
+            bk.fc1 = get_linear(wt, bp + "mlp.fc1", hidden, C, true, own);
+            bk.fc1.act = ACT_GELU_ERF;                                  // swin.rs:105
+            bk.fc2 = get_linear(wt, bp + "mlp.fc2", C, hidden, true, own);
+            const float* table = wt.get(bp + "attn.relative_position_bias_table", {T, heads})->data;
+            // biasT[h][key][query] = table[index[query][key]][h], index = (i-k+ws-1)*(2ws-1) + (j-l+ws-1) (swin.rs:182-184)
+            std::vector<float> bt((size_t)heads * N * N);
+            for (int q = 0; q < N; ++q) {
+                const int qi = q / ws, qj = q % ws;
+                for (int k = 0; k < N; ++k) {
+                    const int ki = k / ws, kj = k % ws;
+                    const int idx = (qi - ki + ws - 1) * (2 * ws - 1) + (qj - kj + ws - 1);
+                    for (int h = 0; h < heads; ++h) bt[((size_t)h * N + k) * N + q] = table[(size_t)idx * heads + h];
+                }
+            }
+            bk.biasT = own.upload(bt);
+        }
+        st.has_down = i < 3;
+        if (st.has_down) {
+            st.down_norm = get_ln(wt, lp + "downsample.norm", 4 * C, own);
+            st.reduction = get_linear(wt, lp + "downsample.reduction", 2 * C, 4 * C, false, own);
+        }
+        st.out_norm = get_ln(wt, pre + "norm" + std::to_string(i), C, own);
+    }
+}
+
+// ---- BasicDecBlk + ASPPDeformable (decoder.rs:86-124, aspp.rs:236-300) ---------------------------------------------------
+static GemmW conv_bn(const WeightTable& wt, const std::string& conv, bool has_bias, const std::string& bn, int O, int Cin,
+                     int cinp, int k, int pad, int act, DeviceOwner& own) {
+    const float* w = wt.get(conv + ".weight", {O, Cin, k, k})->data;
+    const float* b = has_bias ? wt.get(conv + ".bias", {O})->data : nullptr;
+    GemmW g = make_conv_nhwc(own, w, nullptr, O, Cin, cinp, k, k, 1, pad, 1);
+    if (!bn.empty()) {
+        BNHost h = get_bn(wt, bn, O);
+        fold_bn(own, g, b, h.g, h.b, h.m, h.v, 1e-5f);
+    } else if (b) {
+        g.bias = own.upload(b, O);
+    }
+    g.act = act;
+    return g;
+}
+
+void build_decblk_weights(const WeightTable& wt, const std::string& p, int cin, int cout, int deform_mode, DeviceOwner& own,
+                          DecBlkW& out) {
+    const int IC = 64, PL = 256;   // inter_channels (decoder.rs:96), ASPP planes (aspp.rs:243)
+    out.cin = cin; out.cout = cout;
+    if (cin % 32) fail(BRN_ERR_INVALID_ARG, "decoder block in_channels %d must be a multiple of 32", cin);
+    out.conv_in = conv_bn(wt, p + "conv_in", true, p + "bn_in", IC, cin, cin, 3, 1, ACT_RELU, own);
+    out.conv_out = conv_bn(wt, p + "conv_out", true, p + "bn_out", cout, IC, IC, 3, 1, ACT_NONE, own);   // no ReLU (decoder.rs:138-139)
+    ASPPW& a = out.aspp;
+    const std::string ap = p + "dec_att.";
+    const int ks[4] = {1, 1, 3, 7};
+    const std::string mods[4] = {ap + "aspp1.", ap + "aspp_deforms.0.", ap + "aspp_deforms.1.", ap + "aspp_deforms.2."};
+    std::vector<float> pair_w, pair_sc, pair_sh;
+    for (int i = 0; i < 4; ++i) {
+        const int k = ks[i], kk = k * k;
+        DeformW& d = a.d[i];
+        d.k = k;
+        const std::string cp = mods[i] + "atrous_conv.";
+        // all three convs must exist, as DeformConvASPP::new loads them (aspp.rs:39-45)
+        const float* ow = wt.get(cp + "offset_conv.weight", {2 * kk, IC, k, k})->data;
+        const float* ob = wt.get(cp + "offset_conv.bias", {2 * kk})->data;
+        const float* mw = wt.get(cp + "modulator_conv.weight", {kk, IC, k, k})->data;
+        const float* mb = wt.get(cp + "modulator_conv.bias", {kk})->data;
+        d.regular = conv_bn(wt, cp + "regular_conv", false, mods[i] + "bn", PL, IC, IC, k, k / 2, ACT_RELU, own);
+        if (deform_mode == BRN_DEFORM_DEFORMABLE) {
+            d.regular.mode = GEMM_DEFORM_NHWC;
+            std::vector<float> w3((size_t)3 * kk * IC * kk), b3((size_t)3 * kk);
+            memcpy(w3.data(), ow, (size_t)2 * kk * IC * kk * sizeof(float));
+            memcpy(w3.data() + (size_t)2 * kk * IC * kk, mw, (size_t)kk * IC * kk * sizeof(float));
+            memcpy(b3.data(), ob, (size_t)2 * kk * sizeof(float));
+            memcpy(b3.data() + 2 * kk, mb, (size_t)kk * sizeof(float));
+            d.offmod = make_conv_nhwc(own, w3.data(), b3.data(), 3 * kk, IC, IC, k, k, 1, k / 2, 1);
+        }
+    }
+    if (deform_mode == BRN_DEFORM_REFERENCE_CPU) {
+        // aspp1 and aspp_deforms.0 are both plain 1x1 64->256 convs of the same input on the CPU path
+        // (aspp.rs:183-185): one GEMM with N = 512 writes both concat slices.
+        const float* w0 = wt.get(mods[0] + "atrous_conv.regular_conv.weight", {PL, IC, 1, 1})->data;
+        const float* w1 = wt.get(mods[1] + "atrous_conv.regular_conv.weight", {PL, IC, 1, 1})->data;
+        std::vector<float> w2((size_t)2 * PL * IC);
+        memcpy(w2.data(), w0, (size_t)PL * IC * sizeof(float));
+        memcpy(w2.data() + (size_t)PL * IC, w1, (size_t)PL * IC * sizeof(float));
+        a.k1pair = make_linear(own, w2.data(), nullptr, 2 * PL, IC);
+        BNHost h0 = get_bn(wt, mods[0] + "bn", PL), h1 = get_bn(wt, mods[1] + "bn", PL);
+        std::vector<float> g(2 * PL), b(2 * PL), m(2 * PL), v(2 * PL);
+        for (int n = 0; n < PL; ++n) {
+            g[n] = h0.g[n]; b[n] = h0.b[n]; m[n] = h0.m[n]; v[n] = h0.v[n];
+            g[PL + n] = h1.g[n]; b[PL + n] = h1.b[n]; m[PL + n] = h1.m[n]; v[PL + n] = h1.v[n];
+        }
+        fold_bn(own, a.k1pair, nullptr, g.data(), b.data(), m.data(), v.data(), 1e-5f);
+        a.k1pair.act = ACT_RELU;
+    }
+    // global_avg_pool.1 (conv, no bias) + .2 (BN) (aspp.rs:271-278)
+    {
+        const float* gw = wt.get(ap + "global_avg_pool.1.weight", {PL, IC, 1, 1})->data;
+        a.gap_w = own.upload(gw, (size_t)PL * IC);
+        BNHost h = get_bn(wt, ap + "global_avg_pool.2", PL);
+        std::vector<float> sc(PL), sh(PL);
+        for (int n = 0; n < PL; ++n) {
+            const double s = (double)h.g[n] / std::sqrt((double)h.v[n] + 1e-5);
+            sc[n] = (float)s; sh[n] = (float)((0.0 - (double)h.m[n]) * s + (double)h.b[n]);
+        }
+        a.gap_scale = own.upload(sc); a.gap_shift = own.upload(sh);
+    }
+    // conv1 1x1 1280->64 no bias + bn1 + ReLU (aspp.rs:282-290, 329-331).  The first 1024 input channels are the four
+    // spatial branches (a GEMM); the last 256 are the pooled branch, constant over the map -> a per-image bias.
+    {
+        const float* cw = wt.get(ap + "conv1.weight", {IC, 5 * PL, 1, 1})->data;
+        a.conv1_full = own.upload(cw, (size_t)IC * 5 * PL);
+        std::vector<float> mainw((size_t)IC * 4 * PL);
+        for (int o = 0; o < IC; ++o) memcpy(&mainw[(size_t)o * 4 * PL], &cw[(size_t)o * 5 * PL], (size_t)4 * PL * sizeof(float));
+        a.conv1_main = make_linear(own, mainw.data(), nullptr, IC, 4 * PL);
+        BNHost h = get_bn(wt, ap + "bn1", IC);
+        fold_bn(own, a.conv1_main, nullptr, h.g, h.b, h.m, h.v, 1e-5f);
+        a.conv1_main.act = ACT_RELU;
+    }
+}
+
+// ---- BiRefNetDecoder::new (birefnet.rs:170-273) -------------------------------------------------------------------------
+void build_decoder_weights(const WeightTable& wt, const std::string& p, const brn_config& cfg, DeviceOwner& own, DecoderW& out) {
+    int lat[4];
+    brn_config_lateral_channels(&cfg, lat);                      // [384,768,1536,3072]
+    const int ipt_out[5] = {48, 96, 192, 384, 384};              // birefnet.rs:180
+    const int ipt_in[5] = {3, ipt_out[0], lat[0] / 2, lat[2] / 2, lat[3]};   // birefnet.rs:189-193
+    // what image2patches really delivers at each scale (birefnet.rs:304-316): 3*g*g channels
+    const int patch_ch[5] = {3, 48, 192, 768, 3072};
+    for (int i = 0; i < 5; ++i)
+        if (ipt_in[i] != patch_ch[i])
+            fail(BRN_ERR_INVALID_ARG, "ipt_blk%d expects %d channels but image2patches yields %d: only the Swin-L channel plan "
+                 "[192,384,768,1536] with mul_scl_ipt is self-consistent in the reference (birefnet.rs:189-193,304-316)",
+                 i + 1, ipt_in[i], patch_ch[i]);
+    // ipt_blk1: conv1 reads the NCHW image directly; conv_out (64->48) is composed with conv_out1's ipt slice below
+    {
+        const std::string ip = p + "ipt_blk1.";
+        const float* w = wt.get(ip + "conv1.weight", {64, 3, 3, 3})->data;
+        const float* b = wt.get(ip + "conv1.bias", {64})->data;
+        out.ipt[0].conv1 = make_conv_gather(own, w, b, 64, 3, 3, 3, 1, 1, 1);
+    }
+    for (int i = 1; i < 5; ++i) {
+        const std::string ip = p + "ipt_blk" + std::to_string(i + 1) + ".";
+        const int cin = ipt_in[i], cinp = roundup(cin, 32);
+        const float* w = wt.get(ip + "conv1.weight", {64, cin, 3, 3})->data;
+        const float* b = wt.get(ip + "conv1.bias", {64})->data;
+        out.ipt[i].conv1 = make_conv_nhwc(own, w, b, 64, cin, cinp, 3, 3, 1, 1, 1);
+        const float* w2 = wt.get(ip + "conv_out.weight", {ipt_out[i], 64, 3, 3})->data;
+        const float* b2 = wt.get(ip + "conv_out.bias", {ipt_out[i]})->data;
+        out.ipt[i].conv_out = make_conv_nhwc(own, w2, b2, ipt_out[i], 64, 64, 3, 3, 1, 1, 1);
+    }
+    const int dec_out[4] = {lat[2], lat[1], lat[0], lat[0] / 2};          // [1536,768,384,192] birefnet.rs:202
+    const int dec_in[4] = {lat[3] + ipt_out[4], dec_out[0] + ipt_out[3], dec_out[1] + ipt_out[2], dec_out[2] + ipt_out[1]};
+    const char* dnames[4] = {"decoder_block4.", "decoder_block3.", "decoder_block2.", "decoder_block1."};
+    for (int i = 0; i < 4; ++i)
+        build_decblk_weights(wt, p + dnames[i], dec_in[i], dec_out[i], cfg.deform_mode, own, out.dec[i]);
+    const char* lnames[3] = {"lateral_block4.conv", "lateral_block3.conv", "lateral_block2.conv"};
+    const int lch[3] = {lat[2], lat[1], lat[0]};
+    for (int i = 0; i < 3; ++i) {
+        const float* w = wt.get(p + lnames[i] + ".weight", {lch[i], lch[i], 1, 1})->data;
+        const float* b = wt.get(p + lnames[i] + ".bias", {lch[i]})->data;
+        out.lat[i] = make_linear(own, w, b, lch[i], lch[i]);
+    }
+    const char* sfx[3] = {"4", "3", "2"};
+    for (int i = 0; i < 3; ++i) {
+        const std::string gp = p + "gdt_convs_" + sfx[i];
+        out.gdt[i] = conv_bn(wt, gp + ".0", true, gp + ".1", 16, dec_out[i], dec_out[i], 3, 1, ACT_RELU, own);
+        const std::string apn = p + "gdt_convs_attn_" + sfx[i] + ".0";
+        out.gdt_attn_w[i] = own.upload(wt.get(apn + ".weight", {1, 16, 1, 1})->data, 16);
+        out.gdt_attn_b[i] = wt.get(apn + ".bias", {1})->data[0];
+        // loaded-but-unused heads must exist (birefnet.rs:230-232, 241-243)
+        const std::string ppn = p + "gdt_convs_pred_" + sfx[i] + ".0";
+        (void)wt.get(ppn + ".weight", {1, 16, 1, 1}); (void)wt.get(ppn + ".bias", {1});
+        const std::string msn = p + "conv_ms_spvn_" + sfx[i];
+        (void)wt.get(msn + ".weight", {1, dec_out[i], 1, 1}); (void)wt.get(msn + ".bias", {1});
+    }
+    // conv_out1.0: 1x1, 240 -> 1 (birefnet.rs:237-238).  w[0:192] acts on p1 (at 1/4 resolution, see final_head_kernel);
+    // w[192:240] acts on ipt1 = ipt_blk1.conv_out(u) + b: composed here into one 3x3 64->1 stencil (fp64 accumulate).
+    {
+        const int fin = dec_out[3] + ipt_out[0];
+        const float* ow = wt.get(p + "conv_out1.0.weight", {1, fin, 1, 1})->data;
+        out.out_b = wt.get(p + "conv_out1.0.bias", {1})->data[0];
+        out.out_w = own.upload(ow, fin);
+        const float* w2 = wt.get(p + "ipt_blk1.conv_out.weight", {ipt_out[0], 64, 3, 3})->data;
+        const float* b2 = wt.get(p + "ipt_blk1.conv_out.bias", {ipt_out[0]})->data;
+        std::vector<float> tw(9 * 64);
+        for (int t = 0; t < 9; ++t)
+            for (int ci = 0; ci < 64; ++ci) {
+                double s = 0.0;
+                for (int o = 0; o < ipt_out[0]; ++o) s += (double)ow[dec_out[3] + o] * (double)w2[((size_t)o * 64 + ci) * 9 + t];
+                tw[t * 64 + ci] = (float)s;
+            }
+        double tb = 0.0;
+        for (int o = 0; o < ipt_out[0]; ++o) tb += (double)ow[dec_out[3] + o] * (double)b2[o];
+        out.tail_w = own.upload(tw);
+        out.tail_b = (float)tb;
+    }
+}
+
+}  // namespace brn

@@ -1,0 +1,354 @@
+// elementwise.hip — the HBM-bound data-movement kernels of the path (channels-last, float4 per lane).
+// Each one names the reference tensor op(s) it stands for.
+#include "../brn_kernels.h"
+
+namespace brn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline dim3 grid1d(size_t n, int block) {
+    size_t g = (n + block - 1) / block;
+    if (g > 65535u * 32u) g = 65535u * 32u;   // kernels grid-stride
+    if (g == 0) g = 1;
+    return dim3((unsigned)g);
+}
+
+// PyTorch/candle align_corners=true source coordinate: src = dst * (in-1)/(out-1) (0 when out == 1)
+__device__ __forceinline__ void ac_coord(int dst, int in, int out, int& i0, int& i1, float& l) {
+    const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    const float src = scale * (float)dst;
+    i0 = (int)src;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l = src - (float)i0;
+}
+
+// Tensor::upsample_bilinear2d(h, w, true) on a channels-last window (birefnet.rs:332,347,362,435-438,450-452)
+__global__ void resize_nhwc_kernel(const float* __restrict__ x, int B, int Hin, int Win, int C4, int ldx, int x_coff,
+                                   float* __restrict__ y, int Hout, int Wout, int ldy, int y_coff) {
+    const size_t total = (size_t)B * Hout * Wout * C4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % C4);
+        size_t pix = idx / C4;
+        const int ox = (int)(pix % Wout); pix /= Wout;
+        const int oy = (int)(pix % Hout);
+        const int b = (int)(pix / Hout);
+        int y0, y1, x0, x1; float ly, lx;
+        ac_coord(oy, Hin, Hout, y0, y1, ly);
+        ac_coord(ox, Win, Wout, x0, x1, lx);
+        const float* base = x + (size_t)b * Hin * Win * ldx + x_coff + c4 * 4;
+        const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * Win + x0) * ldx);
+        const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * Win + x1) * ldx);
+        const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * Win + x0) * ldx);
+        const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * Win + x1) * ldx);
+        const f32x4 top = v00 + (v01 - v00) * lx;
+        const f32x4 bot = v10 + (v11 - v10) * lx;
+        const f32x4 r = top + (bot - top) * ly;
+        *reinterpret_cast<f32x4*>(y + (((size_t)b * Hout + oy) * Wout + ox) * ldy + y_coff + c4 * 4) = r;
+    }
+}
+
+hipError_t launch_resize_nhwc(const float* x, int B, int Hin, int Win, int C, int ldx, int x_coff,
+                              float* y, int Hout, int Wout, int ldy, int y_coff, hipStream_t s) {
+    if (C % 4 || ldx % 4 || ldy % 4 || x_coff % 4 || y_coff % 4) return hipErrorInvalidValue;
+    const size_t total = (size_t)B * Hout * Wout * (C / 4);
+    hipLaunchKernelGGL(resize_nhwc_kernel, grid1d(total, 256), dim3(256), 0, s, x, B, Hin, Win, C / 4, ldx, x_coff,
+                       y, Hout, Wout, ldy, y_coff);
+    return hipGetLastError();
+}
+
+// planar (NCHW) variant for the 3-channel image -> half scale (birefnet.rs:425)
+__global__ void resize_nchw_kernel(const float* __restrict__ x, int BC, int Hin, int Win, float* __restrict__ y,
+                                   int Hout, int Wout) {
+    const size_t total = (size_t)BC * Hout * Wout;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(idx % Wout);
+        size_t t = idx / Wout;
+        const int oy = (int)(t % Hout);
+        const size_t bc = t / Hout;
+        int y0, y1, x0, x1; float ly, lx;
+        ac_coord(oy, Hin, Hout, y0, y1, ly);
+        ac_coord(ox, Win, Wout, x0, x1, lx);
+        const float* base = x + bc * Hin * Win;
+        const float v00 = base[(size_t)y0 * Win + x0], v01 = base[(size_t)y0 * Win + x1];
+        const float v10 = base[(size_t)y1 * Win + x0], v11 = base[(size_t)y1 * Win + x1];
+        const float top = v00 + (v01 - v00) * lx, bot = v10 + (v11 - v10) * lx;
+        y[idx] = top + (bot - top) * ly;
+    }
+}
+hipError_t launch_resize_nchw(const float* x, int BC, int Hin, int Win, float* y, int Hout, int Wout, hipStream_t s) {
+    const size_t total = (size_t)BC * Hout * Wout;
+    hipLaunchKernelGGL(resize_nchw_kernel, grid1d(total, 256), dim3(256), 0, s, x, BC, Hin, Win, y, Hout, Wout);
+    return hipGetLastError();
+}
+
+// NCHW <-> channels-last window, 32x32 tile transpose through LDS (coalesced on both sides)
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, int C, int HW, float* __restrict__ y, int ldy, int y_coff) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, pq = p0 + tx;
+        tile[i][tx] = (c < C && pq < HW) ? x[((size_t)b * C + c) * HW + pq] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int pq = p0 + i, c = c0 + tx;
+        if (pq < HW && c < C) y[((size_t)b * HW + pq) * ldy + y_coff + c] = tile[tx][i];
+    }
+}
+hipError_t launch_nchw_to_nhwc(const float* x, int B, int C, int H, int W, float* y, int ldy, int y_coff, hipStream_t s) {
+    const int HW = H * W;
+    dim3 grid((HW + 31) / 32, (C + 31) / 32, B);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, s, x, C, HW, y, ldy, y_coff);
+    return hipGetLastError();
+}
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, int C, int HW, int ldx, int x_coff, float* __restrict__ y) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int pq = p0 + i, c = c0 + tx;
+        tile[i][tx] = (c < C && pq < HW) ? x[((size_t)b * HW + pq) * ldx + x_coff + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, pq = p0 + tx;
+        if (c < C && pq < HW) y[((size_t)b * C + c) * HW + pq] = tile[tx][i];
+    }
+}
+hipError_t launch_nhwc_to_nchw(const float* x, int B, int C, int H, int W, int ldx, int x_coff, float* y, hipStream_t s) {
+    const int HW = H * W;
+    dim3 grid((HW + 31) / 32, (C + 31) / 32, B);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, s, x, C, HW, ldx, x_coff, y);
+    return hipGetLastError();
+}
+
+// image2patches 'b c (hg h) (wg w) -> b (c hg wg) h w' (birefnet.rs:288-300), written channels-last:
+// y[b][ty][tx][(c*gh + hg)*gw + wg] = x[b][c][hg*th + ty][wg*tw + tx]; channels [Cimg*gh*gw, cpad) are zeroed.
+__global__ void image2patches_kernel(const float* __restrict__ x, int B, int Cimg, int H, int W, int th, int tw,
+                                     float* __restrict__ y, int ldy, int cpad) {
+    const int gh = H / th, gw = W / tw;
+    const int cout = Cimg * gh * gw;
+    const size_t total = (size_t)B * th * tw * cpad;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % cpad);
+        size_t pix = idx / cpad;
+        const int tx = (int)(pix % tw); pix /= tw;
+        const int ty = (int)(pix % th);
+        const int b = (int)(pix / th);
+        float v = 0.f;
+        if (ch < cout) {
+            const int wg = ch % gw, t = ch / gw;
+            const int hg = t % gh, c = t / gh;
+            v = x[(((size_t)b * Cimg + c) * H + hg * th + ty) * W + wg * tw + tx];
+        }
+        y[(((size_t)b * th + ty) * tw + tx) * ldy + ch] = v;
+    }
+}
+hipError_t launch_image2patches(const float* x, int B, int Cimg, int H, int W, int th, int tw,
+                                float* y, int ldy, int cpad, hipStream_t s) {
+    if (H % th || W % tw) return hipErrorInvalidValue;
+    const size_t total = (size_t)B * th * tw * cpad;
+    hipLaunchKernelGGL(image2patches_kernel, grid1d(total, 256), dim3(256), 0, s, x, B, Cimg, H, W, th, tw, y, ldy, cpad);
+    return hipGetLastError();
+}
+
+// x.mean_keepdim(H).mean_keepdim(W) (aspp.rs:314) on a channels-last window: one block per (b, 64-channel group)
+__global__ void gap_nhwc_kernel(const float* __restrict__ x, int HW, int C, int ldx, int x_coff, float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (c < C)
+        for (int pq = part; pq < HW; pq += 4) acc += x[((size_t)b * HW + pq) * ldx + x_coff + c];
+    red[part][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (part == 0 && c < C) out[(size_t)b * C + c] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) / (float)HW;
+}
+hipError_t launch_gap_nhwc(const float* x, int B, int HW, int C, int ldx, int x_coff, float* out, hipStream_t s) {
+    dim3 grid((C + 63) / 64, B);
+    hipLaunchKernelGGL(gap_nhwc_kernel, grid, dim3(256), 0, s, x, HW, C, ldx, x_coff, out);
+    return hipGetLastError();
+}
+
+// tiny dense layer on pooled vectors (global_avg_pool.1 + BN + ReLU, and its projection through conv1; aspp.rs:315-317,329)
+__global__ void small_fc_kernel(const float* __restrict__ x, int Cin, const float* __restrict__ w, int ldw, int w_off, int N,
+                                const float* __restrict__ scale, const float* __restrict__ shift, int act, float* __restrict__ y) {
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float acc = 0.f;
+    for (int k = lane; k < Cin; k += 64) acc += x[(size_t)b * Cin + k] * w[(size_t)n * ldw + w_off + k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) {
+        float v = acc;
+        if (scale) v = v * scale[n] + shift[n];
+        if (act == ACT_RELU) v = fmaxf(v, 0.f);
+        y[(size_t)b * N + n] = v;
+    }
+}
+hipError_t launch_small_fc(const float* x, int B, int Cin, const float* w, int ldw, int w_off, int N,
+                           const float* scale, const float* shift, int act, float* y, hipStream_t s) {
+    dim3 grid((N + 3) / 4, B);
+    hipLaunchKernelGGL(small_fc_kernel, grid, dim3(256), 0, s, x, Cin, w, ldw, w_off, N, scale, shift, act, y);
+    return hipGetLastError();
+}
+
+// GDT gate (birefnet.rs:327-329): attn = sigmoid(conv1x1_16->1(g)); p *= attn (broadcast over channels).
+// One wave per pixel: lanes 0..15 read g, wave-reduce, then the whole wave scales the C channels.
+__global__ void gdt_gate_kernel(float* __restrict__ p, size_t npix, int C4, int ldp, int p_coff, const float* __restrict__ g,
+                                int ldg, const float* __restrict__ w, float bias) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const size_t nwaves = (size_t)gridDim.x * (blockDim.x >> 6);
+    for (size_t pix = wave; pix < npix; pix += nwaves) {
+        float d = lane < 16 ? g[pix * ldg + lane] * w[lane] : 0.f;
+        d += __shfl_xor(d, 8); d += __shfl_xor(d, 4); d += __shfl_xor(d, 2); d += __shfl_xor(d, 1);
+        d = __shfl(d, 0);
+        const float a = 1.0f / (1.0f + expf(-(d + bias)));
+        float* row = p + pix * ldp + p_coff;
+        for (int c4 = lane; c4 < C4; c4 += 64) {
+            f32x4 v = *reinterpret_cast<f32x4*>(row + c4 * 4);
+            *reinterpret_cast<f32x4*>(row + c4 * 4) = v * a;
+        }
+    }
+}
+hipError_t launch_gdt_gate(float* p, int npix, int C, int ldp, int p_coff, const float* g, int ldg,
+                           const float* w, float bias, hipStream_t s) {
+    if (C % 4) return hipErrorInvalidValue;
+    size_t blocks = ((size_t)npix + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(gdt_gate_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, (size_t)npix, C / 4, ldp, p_coff, g, ldg, w, bias);
+    return hipGetLastError();
+}
+
+// per-pixel dot product over channels: y[pix] = <x[pix][0:C], w> + bias.  16 lanes per pixel.
+__global__ void pixel_dot_kernel(const float* __restrict__ x, size_t npix, int C4, int ldx, int x_coff,
+                                 const float* __restrict__ w, float bias, float* __restrict__ y) {
+    const int sub = threadIdx.x & 15;
+    const size_t grp = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const size_t ngrp = ((size_t)gridDim.x * blockDim.x) >> 4;
+    for (size_t pix = grp; pix < npix; pix += ngrp) {
+        const float* row = x + pix * ldx + x_coff;
+        float acc = 0.f;
+        for (int c4 = sub; c4 < C4; c4 += 16) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(row + c4 * 4);
+            const f32x4 ww = *reinterpret_cast<const f32x4*>(w + c4 * 4);
+            acc += (v[0] * ww[0] + v[1] * ww[1]) + (v[2] * ww[2] + v[3] * ww[3]);
+        }
+        acc += __shfl_xor(acc, 8); acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 1);
+        if (sub == 0) y[pix] = acc + bias;
+    }
+}
+hipError_t launch_pixel_dot(const float* x, int npix, int C, int ldx, int x_coff, const float* w, float bias,
+                            float* y, hipStream_t s) {
+    if (C % 4) return hipErrorInvalidValue;
+    size_t blocks = ((size_t)npix * 16 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(pixel_dot_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, (size_t)npix, C / 4, ldx, x_coff, w, bias, y);
+    return hipGetLastError();
+}
+
+// Final head.  The reference upsamples p1 x4 (192 ch), concatenates ipt1 (48 ch) and applies conv_out1 1x1 240->1
+// (birefnet.rs:372-375).  Both the bilinear upsample (weights sum to 1) and the 1x1 conv are linear, so
+// conv(up(p1)) == up(conv(p1)): q = <p1, w[0:192]> is computed at 1/4 resolution and upsampled here, t = <ipt1, w[192:240]>.
+__global__ void final_head_kernel(const float* __restrict__ q, int B, int h, int w, const float* __restrict__ t, float bias,
+                                  int H, int W, int apply_sigmoid, float* __restrict__ out) {
+    const size_t total = (size_t)B * H * W;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(idx % W);
+        size_t tt = idx / W;
+        const int oy = (int)(tt % H);
+        const size_t b = tt / H;
+        int y0, y1, x0, x1; float ly, lx;
+        ac_coord(oy, h, H, y0, y1, ly);
+        ac_coord(ox, w, W, x0, x1, lx);
+        const float* base = q + b * h * w;
+        const float v00 = base[(size_t)y0 * w + x0], v01 = base[(size_t)y0 * w + x1];
+        const float v10 = base[(size_t)y1 * w + x0], v11 = base[(size_t)y1 * w + x1];
+        const float top = v00 + (v01 - v00) * lx, bot = v10 + (v11 - v10) * lx;
+        float v = (top + (bot - top) * ly) + t[idx] + bias;
+        if (apply_sigmoid) v = 1.0f / (1.0f + expf(-v));
+        out[idx] = v;
+    }
+}
+hipError_t launch_final_head(const float* q, int B, int h, int w, const float* t, float bias, int H, int W,
+                             int apply_sigmoid, float* out, hipStream_t s) {
+    const size_t total = (size_t)B * H * W;
+    hipLaunchKernelGGL(final_head_kernel, grid1d(total, 256), dim3(256), 0, s, q, B, h, w, t, bias, H, W, apply_sigmoid, out);
+    return hipGetLastError();
+}
+
+__global__ void sigmoid_kernel(const float* __restrict__ x, size_t n, float* __restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = 1.0f / (1.0f + expf(-x[i]));
+}
+hipError_t launch_sigmoid(const float* x, size_t n, float* y, hipStream_t s) {
+    hipLaunchKernelGGL(sigmoid_kernel, grid1d(n, 256), dim3(256), 0, s, x, n, y);
+    return hipGetLastError();
+}
+
+// modulator = 2 / (1 + exp(-x))  (aspp.rs:173-174) applied in place to columns [c0, c1)
+__global__ void mod_sigmoid2_kernel(float* __restrict__ x, size_t rows, int ld, int c0, int c1) {
+    const int nc = c1 - c0;
+    const size_t total = rows * nc;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / nc; const int c = (int)(i - r * nc);
+        float* ptr = x + r * ld + c0 + c;
+        *ptr = (1.0f / (1.0f + expf(-*ptr))) * 2.0f;
+    }
+}
+hipError_t launch_mod_sigmoid2(float* x, size_t rows, int ld, int c0, int c1, hipStream_t s) {
+    hipLaunchKernelGGL(mod_sigmoid2_kernel, grid1d(rows * (size_t)(c1 - c0), 256), dim3(256), 0, s, x, rows, ld, c0, c1);
+    return hipGetLastError();
+}
+
+// 3x3 conv (pad 1, stride 1) of a channels-last map to ONE output channel: y[pix] = b + sum_taps <x[pix+tap][0:C], w[tap][0:C]>.
+// Used for the ipt_blk1 tail: conv_out1's slice over ipt1 (1x1, 48->1; birefnet.rs:374-375) composed at load time with
+// ipt_blk1.conv_out (3x3, 64->48; decoder.rs:45,54) — two linear maps with no activation between them (decoder.rs:52).
+// 16 lanes per pixel, one float4 of channels per lane and tap (C == 64).
+__global__ void conv3x3_to1_kernel(const float* __restrict__ x, int B, int H, int W, int ldx, const float* __restrict__ w,
+                                   float bias, float* __restrict__ y) {
+    const int sub = threadIdx.x & 15;
+    const size_t npix = (size_t)B * H * W;
+    const size_t grp = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const size_t ngrp = ((size_t)gridDim.x * blockDim.x) >> 4;
+    f32x4 wr[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wr[t] = *reinterpret_cast<const f32x4*>(w + t * 64 + sub * 4);
+    for (size_t pix = grp; pix < npix; pix += ngrp) {
+        const int ox = (int)(pix % W);
+        const size_t t2 = pix / W;
+        const int oy = (int)(t2 % H);
+        const size_t b = t2 / H;
+        float acc = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy + ky - 1;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox + kx - 1;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((b * H + iy) * W + ix) * ldx + sub * 4);
+                const f32x4 ww = wr[ky * 3 + kx];
+                acc += (v[0] * ww[0] + v[1] * ww[1]) + (v[2] * ww[2] + v[3] * ww[3]);
+            }
+        }
+        acc += __shfl_xor(acc, 8); acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 1);
+        if (sub == 0) y[pix] = acc + bias;
+    }
+}
+hipError_t launch_conv3x3_to1(const float* x, int B, int H, int W, int C, int ldx, const float* w, float bias,
+                              float* y, hipStream_t s) {
+    if (C != 64) return hipErrorInvalidValue;
+    size_t blocks = ((size_t)B * H * W * 16 + 255) / 256;
+    if (blocks > 32768) blocks = 32768;
+    hipLaunchKernelGGL(conv3x3_to1_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, B, H, W, ldx, w, bias, y);
+    return hipGetLastError();
+}
+
+}  // namespace brn

@@ -1,0 +1,270 @@
+// gemm_f32.hip — the one contraction kernel of the path: C = epilogue(A_gather[M,K] x W[N,K]^T) in exact fp32
+// on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain, 64 FLOP/clk/SIMD).
+//
+// It replaces every candle Linear / Conv2d the reference's hot path executes:
+//   GEMM_DENSE        candle_nn::linear (swin.rs:98-99,130-131,487) and all 1x1 convs (decoder.rs:65, aspp.rs:271,282)
+//   GEMM_CONV_NHWC    candle_nn::conv2d 3x3 / 7x7 (decoder.rs:44-45,104,113; aspp.rs:39-45; birefnet.rs:105)
+//   GEMM_GATHER_NCHW  the two convs that read the NCHW image directly: PatchEmbed.proj 4x4 s4 (swin.rs:677) and
+//                     ipt_blk1.conv1 3x3 (birefnet.rs:189)
+//   GEMM_DEFORM_NHWC  the Metal path's deformable_im2col + matmul (aspp.rs:58-165) with the column matrix never
+//                     materialised: the bilinear gather * modulator is the A-tile loader
+// with bias / folded eval-BatchNorm / ReLU / erf-GELU / residual / concat-slice writes fused into the epilogue.
+//
+// Tiling (wave64): block tile BMxBN, BK = 32; WMxWN waves, each owning (BM/WM)x(BN/WN) as 32x32 MFMA tiles.
+// The k index inside a BK tile is permuted: lane-half h of an MFMA step s contracts k = 16h + s, so a lane's
+// sixteen A (or B) values of a tile are 16 consecutive floats of one LDS row = four ds_read_b128 (row stride
+// 36 floats: conflict-free for the b128 lane groups).  Global->LDS goes through registers (one float4 per
+// thread per 32 rows) with the next tile's loads in flight during the current tile's 64-cycle MFMAs.
+#include "../brn_kernels.h"
+
+namespace brn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+
+constexpr int BK = 32;
+constexpr int LDS_LD = 36;
+
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+template <int BM, int BN, int WM, int WN, int MODE>
+__global__ void __launch_bounds__(WM* WN * 64) gemm_f32_kernel(const GemmParams p) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int RPP = NT / 8;  // tile rows covered by one pass of float4 loads (8 float4 = one 32-float row)
+    constexpr int PA = BM / RPP, PB = BN / RPP;
+    constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+    static_assert(PA >= 1 && PB >= 1 && TM >= 1 && TN >= 1, "tile too small for the thread count");
+
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_LD];
+    float* As = smem;
+    float* Bs = smem + BM * LDS_LD;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware tile order: blocks that share an XCD (same blockIdx % 8) walk a contiguous run of tiles,
+    // n fastest, so an A panel is fetched into that XCD's L2 once for all its N tiles (bijective remap).
+    const int tilesN = (p.N + BN - 1) / BN;
+    int swz;
+    {
+        const int nwg = gridDim.x, orig = blockIdx.x;
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int m0 = (swz / tilesN) * BM, n0 = (swz % tilesN) * BN;
+
+    const int kq = tid & 7, lrow = tid >> 3;
+
+    // ---- per-row gather state (fixed over the K loop) ----
+    long a_base[PA];
+    int a_iy[PA], a_ix[PA];
+    bool a_ok[PA];
+    long om_base[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int m = m0 + lrow + i * RPP;
+        a_ok[i] = m < p.M;
+        a_iy[i] = 0; a_ix[i] = 0; om_base[i] = 0;
+        if (MODE == GEMM_DENSE) {
+            a_base[i] = (long)m * p.lda;
+        } else {
+            const int hw = p.Hout * p.Wout;
+            const int b = m / hw, rem = m - b * hw;
+            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+            a_iy[i] = oy * p.stride - p.pad;
+            a_ix[i] = ox * p.stride - p.pad;
+            if (MODE == GEMM_GATHER_NCHW) a_base[i] = (long)b * p.Cin * p.Hin * p.Win;
+            else a_base[i] = (long)b * p.Hin * p.Win * p.lda + p.a_coff;
+            om_base[i] = (long)m * p.om_ld;
+        }
+    }
+    const float* wrow = p.W + (long)(n0 + lrow) * p.K + kq * 4;
+
+    f32x4 ra[PA], rb[PB];
+
+    auto gload = [&](int kt) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < PB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wrow + (long)i * RPP * p.K + k0);
+        if (MODE == GEMM_DENSE) {
+#pragma unroll
+            for (int i = 0; i < PA; ++i)
+                ra[i] = a_ok[i] ? *reinterpret_cast<const f32x4*>(p.A + a_base[i] + k0 + kq * 4)
+                                : zero4();
+        } else if (MODE == GEMM_CONV_NHWC) {
+            const int tap = k0 / p.Cin, ci0 = k0 - tap * p.Cin;
+            const int ky = tap / p.kw, kx = tap - ky * p.kw;
+            const int dy = ky * p.dil, dx = kx * p.dil;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
+                const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+                ra[i] = ok ? *reinterpret_cast<const f32x4*>(p.A + a_base[i] + ((long)iy * p.Win + ix) * p.lda +
+                                                              ci0 + kq * 4)
+                           : zero4();
+            }
+        } else if (MODE == GEMM_GATHER_NCHW) {
+            const int khw = p.kh * p.kw;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = k0 + kq * 4 + e;
+                    const int c = k / khw, rem = k - c * khw;
+                    const int ky = rem / p.kw, kx = rem - ky * p.kw;
+                    const int iy = a_iy[i] + ky * p.dil, ix = a_ix[i] + kx * p.dil;
+                    const bool ok = a_ok[i] && k < p.Kreal && (unsigned)iy < (unsigned)p.Hin &&
+                                    (unsigned)ix < (unsigned)p.Win;
+                    v[e] = ok ? p.A[a_base[i] + ((long)c * p.Hin + iy) * p.Win + ix] : 0.f;
+                }
+                { f32x4 t = {v[0], v[1], v[2], v[3]}; ra[i] = t; }
+            }
+        } else {  // GEMM_DEFORM_NHWC: torchvision deform_conv2d sampling, 1 offset group, modulated
+            const int tap = k0 / p.Cin, ci0 = k0 - tap * p.Cin;
+            const int ky = tap / p.kw, kx = tap - ky * p.kw;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                f32x4 r = zero4();
+                if (a_ok[i]) {
+                    const float* omr = p.om + om_base[i];
+                    const float offy = omr[2 * tap], offx = omr[2 * tap + 1];
+                    const float mk = omr[p.om_mask_off + tap];
+                    const float y = (float)(a_iy[i] + ky * p.dil) + offy;
+                    const float x = (float)(a_ix[i] + kx * p.dil) + offx;
+                    if (y > -1.f && y < (float)p.Hin && x > -1.f && x < (float)p.Win) {
+                        const int yl = (int)floorf(y), xl = (int)floorf(x);
+                        const int yh = yl + 1, xh = xl + 1;
+                        const float ly = y - (float)yl, lx = x - (float)xl;
+                        const float hy = 1.f - ly, hx = 1.f - lx;
+                        const float* base = p.A + a_base[i] + ci0 + kq * 4;
+                        f32x4 v1 = zero4(), v2 = v1, v3 = v1, v4 = v1;
+                        if (yl >= 0 && xl >= 0) v1 = *reinterpret_cast<const f32x4*>(base + ((long)yl * p.Win + xl) * p.lda);
+                        if (yl >= 0 && xh <= p.Win - 1) v2 = *reinterpret_cast<const f32x4*>(base + ((long)yl * p.Win + xh) * p.lda);
+                        if (yh <= p.Hin - 1 && xl >= 0) v3 = *reinterpret_cast<const f32x4*>(base + ((long)yh * p.Win + xl) * p.lda);
+                        if (yh <= p.Hin - 1 && xh <= p.Win - 1) v4 = *reinterpret_cast<const f32x4*>(base + ((long)yh * p.Win + xh) * p.lda);
+                        const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+                        r = mk * (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4);
+                    }
+                }
+                ra[i] = r;
+            }
+        }
+    };
+    auto lds_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+            *reinterpret_cast<f32x4*>(As + (lrow + i * RPP) * LDS_LD + kq * 4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+            *reinterpret_cast<f32x4*>(Bs + (lrow + i * RPP) * LDS_LD + kq * 4) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = p.K / BK;
+    const float* a_frag = As + (wm * WTM + (lane & 31)) * LDS_LD + (lane >> 5) * 16;
+    const float* b_frag = Bs + (wn * WTN + (lane & 31)) * LDS_LD + (lane >> 5) * 16;
+
+    gload(0);
+    lds_store();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+        for (int hs = 0; hs < 2; ++hs) {
+            float af[TM][8], bf[TN][8];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(a_frag + i * 32 * LDS_LD + hs * 8);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(a_frag + i * 32 * LDS_LD + hs * 8 + 4);
+                af[i][0] = v0.x; af[i][1] = v0.y; af[i][2] = v0.z; af[i][3] = v0.w;
+                af[i][4] = v1.x; af[i][5] = v1.y; af[i][6] = v1.z; af[i][7] = v1.w;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(b_frag + j * 32 * LDS_LD + hs * 8);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(b_frag + j * 32 * LDS_LD + hs * 8 + 4);
+                bf[j][0] = v0.x; bf[j][1] = v0.y; bf[j][2] = v0.z; bf[j][3] = v0.w;
+                bf[j][4] = v1.x; bf[j][5] = v1.y; bf[j][6] = v1.z; bf[j][7] = v1.w;
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (kt + 1 < nk) {
+            lds_store();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+    const int col = lane & 31, rhalf = (lane >> 5) * 4;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WTN + j * 32 + col;
+        if (n >= p.N) continue;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+        const float sc = p.scale ? p.scale[n] : 1.f;
+        const float sh = p.shift ? p.shift[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r] + bias;
+                if (p.bbias) v += p.bbias[(long)(m / p.bbias_rows) * p.N + n];
+                if (p.scale) v = v * sc + sh;
+                if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+                else if (p.act == ACT_GELU_ERF) v = gelu_erf(v);
+                if (p.R) v += p.R[(long)m * p.ldr + p.r_coff + n];
+                p.C[(long)m * p.ldc + p.c_coff + n] = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static hipError_t launch_cfg(const GemmParams& p, hipStream_t s) {
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    dim3 grid(tiles), block(WM * WN * 64);
+    switch (p.mode) {
+        case GEMM_DENSE: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, GEMM_DENSE>), grid, block, 0, s, p); break;
+        case GEMM_CONV_NHWC: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, GEMM_CONV_NHWC>), grid, block, 0, s, p); break;
+        case GEMM_GATHER_NCHW: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, GEMM_GATHER_NCHW>), grid, block, 0, s, p); break;
+        case GEMM_DEFORM_NHWC: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, GEMM_DEFORM_NHWC>), grid, block, 0, s, p); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0) return hipErrorInvalidValue;
+    if ((p.mode == GEMM_CONV_NHWC || p.mode == GEMM_DEFORM_NHWC) && (p.Cin % BK) != 0) return hipErrorInvalidValue;
+    // tile choice: the widest tile that still gives the 256 CUs >= ~2 workgroups each, and no wider in N
+    // than the problem.  W is padded to 128 rows so every config may over-read it safely.
+    const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    const long t12864 = (long)((p.M + 127) / 128) * ((p.N + 63) / 64);
+    const bool n_fits64 = ((p.N + 63) / 64) * 64 < ((p.N + 127) / 128) * 128;  // a 64-wide tile wastes less
+    if (t128 >= 512 && !n_fits64) return launch_cfg<128, 128, 2, 2>(p, s);
+    if (t12864 >= 512) return launch_cfg<128, 64, 2, 2>(p, s);
+    if (t128 >= 384 && !n_fits64) return launch_cfg<128, 128, 2, 2>(p, s);
+    return launch_cfg<64, 64, 2, 2>(p, s);
+}
+
+}  // namespace brn

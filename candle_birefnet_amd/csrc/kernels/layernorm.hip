@@ -1,0 +1,83 @@
+// layernorm.hip — candle_nn::layer_norm forward (swin.rs:333,335,486,680,754), one wave64 per row, the row kept
+// in registers (two-pass mean / biased variance, eps inside the sqrt), float4 loads and stores.  HBM-bound.
+// mode 1 fuses PatchMerging's 2x2 strided gather + concat (swin.rs:505-522) into the load.
+#include "../brn_kernels.h"
+
+namespace brn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int LN_MAX_V = 12;   // float4 per lane: C <= 64*4*12 = 3072
+constexpr int LN_WAVES = 4;
+
+template <int MODE>
+__global__ void __launch_bounds__(LN_WAVES * 64) layernorm_kernel(const LayerNormParams p) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const int nv = p.C >> 2;   // float4 per row
+    f32x4 v[LN_MAX_V];
+    int h2 = 0, w2 = 0, bi = 0, Ho = 0, Wo = 0;
+    if (MODE == 1) {
+        Ho = (p.H + 1) >> 1; Wo = (p.W + 1) >> 1;
+        const int hw = Ho * Wo;
+        bi = (int)(row / hw);
+        const int rem = (int)(row - (long)bi * hw);
+        h2 = rem / Wo; w2 = rem - h2 * Wo;
+    }
+    const int cin4 = p.Cin >> 2;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_V; ++i) {
+        const int c4 = lane + i * 64;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (c4 < nv) {
+            if (MODE == 0) {
+                t = *reinterpret_cast<const f32x4*>(p.x + row * p.ldx + c4 * 4);
+            } else {
+                // concat order (even,even),(odd,even),(even,odd),(odd,odd) in (row,col) — swin.rs:509-519
+                const int part = c4 / cin4, cc = c4 - part * cin4;
+                const int y = 2 * h2 + (part & 1), x = 2 * w2 + (part >> 1);
+                if (y < p.H && x < p.W)
+                    t = *reinterpret_cast<const f32x4*>(p.x + (((long)bi * p.H + y) * p.W + x) * p.Cin + cc * 4);
+            }
+            sum += (t[0] + t[1]) + (t[2] + t[3]);
+        }
+        v[i] = t;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)p.C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_V; ++i) {
+        if (lane + i * 64 < nv) {
+            const f32x4 d = v[i] - mean;
+            sq += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = 1.0f / sqrtf(sq / (float)p.C + p.eps);
+    float* yrow = p.y + row * p.ldy + p.y_coff;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_V; ++i) {
+        const int c4 = lane + i * 64;
+        if (c4 < nv) {
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + c4 * 4);
+            const f32x4 bt = *reinterpret_cast<const f32x4*>(p.beta + c4 * 4);
+            *reinterpret_cast<f32x4*>(yrow + c4 * 4) = (v[i] - mean) * rstd * gm + bt;
+        }
+    }
+}
+
+hipError_t launch_layernorm(const LayerNormParams& p, hipStream_t s) {
+    if (p.C % 4 || p.C > 64 * 4 * LN_MAX_V || p.rows <= 0) return hipErrorInvalidValue;
+    if (p.mode == 1 && (p.C != 4 * p.Cin || p.Cin % 4)) return hipErrorInvalidValue;
+    dim3 grid((p.rows + LN_WAVES - 1) / LN_WAVES), block(LN_WAVES * 64);
+    if (p.mode == 0) hipLaunchKernelGGL(layernorm_kernel<0>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace brn

@@ -1,0 +1,196 @@
+/*
+ * birefnet_hip.h — C ABI of libbirefnet_hip.so (MI355X / gfx950 native BiRefNet inference path).
+ *
+ * Every entry point is what the reference crate's FFI for the hot path would bind.  Citations are into
+ * /root/reference (imperatormk/candle-birefnet); the Rust shim a maintainer would add is in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++/torch types.  All tensors are contiguous fp32.
+ *   - brn_status: 0 = ok, non-zero = error; the message is available from brn_last_error() (thread-local).
+ *     No exception or abort crosses the boundary (the one reference panic, swin.rs:352, is an error here).
+ *   - brn_mem says where a caller buffer lives.  BRN_MEM_DEVICE pointers are HIP device pointers of the
+ *     model's device; BRN_MEM_HOST buffers are staged through HBM by the library (H2D/D2H on `stream`).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are asynchronous for
+ *     BRN_MEM_DEVICE buffers and synchronous (stream-synchronised before return) for BRN_MEM_HOST output.
+ *   - image tensors at this boundary are NCHW like candle's (infer_image.rs:67); the library's internal
+ *     layout (NHWC) is not visible.
+ *   - there is NO CPU fallback: every call needs a HIP device and fails with BRN_ERR_NO_DEVICE without one.
+ */
+#ifndef BIREFNET_HIP_H
+#define BIREFNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BRN_ABI_VERSION 1
+
+typedef int brn_status;
+enum {
+    BRN_OK = 0,
+    BRN_ERR_INVALID_ARG = 1,   /* bad shape / null pointer / unsupported config          */
+    BRN_ERR_MISSING_TENSOR = 2,/* weight name absent (candle: Err from vb.get)            */
+    BRN_ERR_SHAPE = 3,         /* weight present with the wrong shape                     */
+    BRN_ERR_NO_DEVICE = 4,     /* no usable HIP device                                    */
+    BRN_ERR_HIP = 5,           /* a HIP runtime call failed                               */
+    BRN_ERR_OOM = 6            /* device workspace allocation failed                      */
+};
+
+typedef enum { BRN_MEM_HOST = 0, BRN_MEM_DEVICE = 1 } brn_mem;
+typedef enum { BRN_F32 = 0 } brn_dtype; /* arithmetic type of the path (reference: DType::F32, infer_image.rs:26) */
+
+/* D1 of SURVEY.md §8: what DeformConvASPP::forward computes.
+ * REFERENCE_CPU = aspp.rs:183-185 (offset/modulator discarded, regular_conv(x)) — the graded parity target.
+ * DEFORMABLE    = aspp.rs:58-165 (Metal path: modulated deformable im2col + matmul).                     */
+typedef enum { BRN_DEFORM_REFERENCE_CPU = 0, BRN_DEFORM_DEFORMABLE = 1 } brn_deform_mode;
+
+/* activation selector of the op-level entry points */
+typedef enum { BRN_ACT_NONE = 0, BRN_ACT_RELU = 1, BRN_ACT_GELU_ERF = 2 } brn_act;
+
+/* Mirrors BiRefNetConfig (birefnet.rs:13-67) + SwinConfig (swin.rs:14-88), field for field,
+ * decorative fields included.  BiRefNet::new ignores `backbone` and always builds swin_l (birefnet.rs:390-391);
+ * here the swin_* fields are honoured so that reduced-depth models can be built for tests. */
+typedef struct brn_config {
+    int size_w, size_h;            /* BiRefNetConfig.size (never read in forward)                  */
+    char backbone[32];             /* "swin_v1_l" (ignored, as in the reference)                   */
+    int backbone_channels[4];      /* [192,384,768,1536]                                           */
+    int mul_scl_ipt;               /* 1                                                            */
+    int ms_supervision;            /* 1 (decorative)                                               */
+    int dec_ipt;                   /* 1 (decorative: decoder always uses ipt blocks)               */
+    int use_aspp_deformable;       /* 1                                                            */
+    int cxt[3]; int n_cxt;         /* [192,384,768], 3                                             */
+    /* SwinConfig */
+    int embed_dim;                 /* 192 */
+    int depths[4];                 /* [2,2,18,2] */
+    int num_heads[4];              /* [6,12,24,48] */
+    int window_size;               /* 12 */
+    float mlp_ratio;               /* 4.0 */
+    int patch_size;                /* 4 */
+    int in_channels;               /* 3 */
+    float drop_path_rate;          /* 0.2 (unused) */
+    /* library-side switch (not in the reference config) */
+    int deform_mode;               /* brn_deform_mode */
+} brn_config;
+
+/* One weight tensor as VarBuilder would hand it over (names: SURVEY.md App. A; shapes as in the safetensors). */
+typedef struct brn_named_tensor {
+    const char* name;
+    const float* data;   /* host pointer, fp32, contiguous; the library copies, the caller keeps ownership */
+    const int64_t* shape;
+    int ndim;
+} brn_named_tensor;
+
+typedef struct brn_model brn_model;     /* BiRefNet (birefnet.rs:380-385) */
+typedef struct brn_swin brn_swin;       /* stand-alone SwinTransformer (swin.rs:718-723) */
+
+/* ---- library ------------------------------------------------------------------------------------------ */
+int brn_abi_version(void);
+const char* brn_last_error(void);               /* thread-local; wrapped into candle_core::Error::Msg by the shim */
+brn_status brn_device_count(int* n);
+const char* brn_build_info(void);               /* "gfx950 hipcc <ver> ..." */
+
+/* ---- config ------------------------------------------------------------------------------------------- */
+/* BiRefNetConfig::swin_l() / Default (birefnet.rs:32-46, 64-66) + SwinConfig::swin_l() (swin.rs:69-80). */
+void brn_config_default_swin_l(brn_config* cfg);
+/* BiRefNetConfig::lateral_channels (birefnet.rs:50-53) and x4_channels (birefnet.rs:56-61). */
+void brn_config_lateral_channels(const brn_config* cfg, int out[4]);
+int brn_config_x4_channels(const brn_config* cfg);
+
+/* ---- model lifecycle: BiRefNet::new (birefnet.rs:389-409) --------------------------------------------- */
+/* Weights are looked up by the names of SURVEY.md App. A below `prefix` ("" for a full checkpoint).
+ * Missing name -> BRN_ERR_MISSING_TENSOR naming it; extra names are ignored.  The loaded-but-unused heads
+ * (gdt_convs_pred_*, conv_ms_spvn_*; birefnet.rs:150-166) must be present, as in the reference.
+ * max_batch/max_h/max_w size the HBM workspace (forward with larger inputs re-plans it). */
+brn_status brn_model_create(const brn_config* cfg, const brn_named_tensor* weights, size_t n_weights,
+                            int device_ordinal, brn_dtype compute_dtype,
+                            int max_batch, int max_h, int max_w, brn_model** out);
+void brn_model_destroy(brn_model* m);
+
+/* BiRefNet::forward_logits (birefnet.rs:412-461): x [B,3,H,W] -> logits [B,1,H,W] (pre-sigmoid).
+ * H and W must be multiples of 32 (the decoder's image2patches, birefnet.rs:288-300, needs it). */
+brn_status brn_forward_logits(brn_model* m, const float* x_nchw, int B, int H, int W, brn_mem in_loc,
+                              float* logits_out, brn_mem out_loc, void* stream);
+/* BiRefNet::forward (birefnet.rs:466-469): sigmoid(forward_logits). */
+brn_status brn_forward(brn_model* m, const float* x_nchw, int B, int H, int W, brn_mem in_loc,
+                       float* mask_out, brn_mem out_loc, void* stream);
+
+/* Pub fields used individually by bench_inference.rs:34,77,83:
+ * model.backbone.forward(x) -> 4 NCHW feature maps (swin.rs:768-797).  outs[i] is [B, C_i, ceil(H/4)/2^i, ...]. */
+brn_status brn_model_backbone_forward(brn_model* m, const float* x_nchw, int B, int H, int W, brn_mem in_loc,
+                                      float* const outs[4], brn_mem out_loc, void* stream);
+/* model.squeeze_module.forward(x4) (birefnet.rs:86-94): [B,5760,h,w] -> [B,3072,h,w]. */
+brn_status brn_model_squeeze_forward(brn_model* m, const float* x4_nchw, int B, int h, int w, brn_mem in_loc,
+                                     float* out, brn_mem out_loc, void* stream);
+/* model.decoder.forward(x, x1, x2, x3, x4) (birefnet.rs:278-376). x [B,3,H,W]; x1..x4 at H/4..H/32 with
+ * 384/768/1536/3072 channels. */
+brn_status brn_model_decoder_forward(brn_model* m, const float* x_nchw, const float* x1, const float* x2,
+                                     const float* x3, const float* x4, int B, int H, int W, brn_mem in_loc,
+                                     float* logits_out, brn_mem out_loc, void* stream);
+
+/* Per-stage wall time of the last forward on this handle, measured with HIP events on the call's stream:
+ * [0]=backbone full, [1]=backbone half+fusion, [2]=squeeze, [3]=decoder, [4]=total (ms).  Mirrors the timers of
+ * bench_inference.rs:37-92.  Enabled by brn_model_set_profiling(m, 1) (adds event records + one sync). */
+brn_status brn_model_set_profiling(brn_model* m, int enable);
+brn_status brn_model_last_timings(brn_model* m, float ms[5]);
+/* Per-kernel-family accounting of the last profiled forward: for family f (see brn_kernel_family_name)
+ * launches[f], ms[f] (HIP-event time around each launch, summed) and flop[f] (2*M*N*K of the launches).
+ * n is the array capacity; returns the number of families through *n_out. */
+brn_status brn_model_last_kernel_stats(brn_model* m, int n, int* launches, float* ms, double* flop,
+                                       double* bytes, int* n_out);
+const char* brn_kernel_family_name(int f);
+
+/* ---- stand-alone SwinTransformer: SwinTransformer::new / forward (swin.rs:725-797) -------------------- */
+brn_status brn_swin_create(const brn_config* cfg /* swin_* fields */, const brn_named_tensor* weights,
+                           size_t n_weights, const char* prefix, int device_ordinal, brn_swin** out);
+void brn_swin_destroy(brn_swin* s);
+brn_status brn_swin_forward(brn_swin* s, const float* x_nchw, int B, int H, int W, brn_mem in_loc,
+                            float* const outs[4], brn_mem out_loc, void* stream);
+
+/* ---- op-level entry points (the candle ops the reference calls; used by the parity tests) -------------- */
+/* candle_nn::linear / linear_no_bias + optional gelu_erf + optional residual (swin.rs:98-107,130-131,406-407):
+ * y[M,N] = act(x[M,K] @ w[N,K]^T + bias) (+ residual[M,N]).  bias/residual may be NULL. */
+brn_status brn_linear_forward(const float* x, int M, int K, const float* w, const float* bias, int N,
+                              int act, const float* residual, float* y, brn_mem loc, int device_ordinal,
+                              void* stream);
+/* candle_nn::layer_norm(dim, eps) forward (swin.rs:333,335,486,680,754): rows of length C. */
+brn_status brn_layer_norm_forward(const float* x, int rows, int C, const float* gamma, const float* beta,
+                                  float eps, float* y, brn_mem loc, int device_ordinal, void* stream);
+/* candle_nn::conv2d / conv2d_no_bias forward (decoder.rs:44-45,104,113; aspp.rs:39-45; swin.rs:677), NCHW,
+ * optional eval-mode batch_norm (decoder.rs:105,129: (x-mean)/sqrt(var+eps)*gamma+beta) and activation fused.
+ * bn = {gamma,beta,running_mean,running_var} each [O] or all NULL. */
+brn_status brn_conv2d_forward(const float* x, int B, int C, int H, int W, const float* w, const float* bias,
+                              int O, int kh, int kw, int stride, int pad, int dil,
+                              const float* bn_gamma, const float* bn_beta, const float* bn_mean,
+                              const float* bn_var, float bn_eps, int act,
+                              float* y, brn_mem loc, int device_ordinal, void* stream);
+/* Tensor::upsample_bilinear2d(h, w, align_corners=true) (birefnet.rs:332,425,435-438,450-452), NCHW. */
+brn_status brn_upsample_bilinear2d(const float* x, int B, int C, int H, int W, int out_h, int out_w,
+                                   float* y, brn_mem loc, int device_ordinal, void* stream);
+/* The attention half of SwinTransformerBlock::forward between norm1 and the residual (swin.rs:356-403):
+ * pad -> roll(-shift) -> window_partition -> WindowAttention::forward (qkv, q*scale, q@k^T + rel-pos bias
+ * (+ SW-MSA mask), softmax, @v, proj) -> window_reverse -> roll(+shift) -> crop.
+ * x [B,H,W,C] is the norm1 output; y [B,H,W,C].  rel_table is relative_position_bias_table [(2ws-1)^2, heads].
+ * head_dim must be 32 and window_size 12 (the Swin-L geometry, swin.rs:69-80). */
+brn_status brn_window_attention_forward(const float* x, int B, int H, int W, int C, int heads, int window_size,
+                                        int shift, const float* qkv_w, const float* qkv_b,
+                                        const float* proj_w, const float* proj_b, const float* rel_table,
+                                        float* y, brn_mem loc, int device_ordinal, void* stream);
+/* PatchMerging::forward (swin.rs:491-527): x [B,H*W,C] -> [B, ceil(H/2)*ceil(W/2), 2C]. */
+brn_status brn_patch_merging_forward(const float* x, int B, int H, int W, int C, const float* norm_g,
+                                     const float* norm_b, const float* reduction_w, float* y, brn_mem loc,
+                                     int device_ordinal, void* stream);
+/* DeformableConv2d::forward (deform_conv.rs:82-99 / :101-215), NCHW.  mode = brn_deform_mode.
+ * offset_w [2k^2,C,k,k]+offset_b, mod_w [k^2,C,k,k]+mod_b, w [O,C,k,k], bias [O] or NULL. */
+brn_status brn_deform_conv2d_forward(const float* x, int B, int C, int H, int W,
+                                     const float* offset_w, const float* offset_b,
+                                     const float* mod_w, const float* mod_b,
+                                     const float* w, const float* bias, int O, int k, int stride, int pad,
+                                     int mode, float* y, brn_mem loc, int device_ordinal, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIREFNET_HIP_H */

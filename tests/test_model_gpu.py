@@ -1,0 +1,59 @@
+"""End-to-end parity of BiRefNet.forward_logits on the GPU against the CPU restatements, at sizes the CPU side finishes
+in seconds.  Gate (BASELINE.json north_star): max abs err <= 1e-3, or <= 1e-2 relative to the reference value."""
+import numpy as np
+import pytest
+import torch
+
+import torch_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(depths, mode="reference_cpu", seed=42):
+    import candle_birefnet_amd as cb
+    cfg = cb.BiRefNetConfig(deform_mode=mode)
+    cfg.swin.depths = list(depths)
+    w = cb.synth_weights(cb.birefnet_weight_spec(cfg), seed=seed)
+    return cb, cfg, w
+
+
+def _gate(y, ref):
+    y, ref = np.asarray(y, np.float64), np.asarray(ref, np.float64)
+    err = np.abs(y - ref)
+    ok = (err <= 1e-3) | (err <= 1e-2 * np.abs(ref))
+    assert ok.all(), f"max abs err {err.max():.3e}, worst rel {np.max(err / np.maximum(np.abs(ref), 1e-12)):.3e}"
+    return float(err.max())
+
+
+@pytest.mark.parametrize("S,B,mode", [(64, 1, "reference_cpu"), (96, 2, "reference_cpu"), (64, 1, "deformable")])
+def test_forward_logits_small_vs_torch(gpu, S, B, mode):
+    cb, cfg, w = _build([2, 2, 2, 2], mode)
+    m = cb.BiRefNet.new(cfg, cb.VarBuilder.from_tensors(w))
+    x = cb.synth_input(B, S, S)
+    y = m.forward_logits(x)
+    assert y.shape == (B, 1, S, S)
+    ref = R.forward_logits(x, w, cfg, torch.float64).numpy()
+    e = _gate(y, ref)
+    print(f"S={S} B={B} {mode}: max abs err vs fp64 restatement {e:.3e}, |logit| max {np.abs(ref).max():.3f}")
+    # forward == sigmoid(forward_logits) (birefnet.rs:466-469)
+    p = m.forward(x)
+    np.testing.assert_allclose(p, 1.0 / (1.0 + np.exp(-y.astype(np.float64))), atol=2e-6)
+    m.close()
+
+
+def test_pieces_vs_torch(gpu):
+    """the pub fields bench_inference.rs drives one by one: backbone, squeeze_module, decoder"""
+    cb, cfg, w = _build([2, 2, 2, 2])
+    m = cb.BiRefNet.new(cfg, cb.VarBuilder.from_tensors(w))
+    S = 64
+    x = cb.synth_input(1, S, S)
+    ref, parts = R.forward_logits(x, w, cfg, torch.float64, return_parts=True)
+    feats = m.backbone.forward(x)
+    for a, b in zip(feats, parts["f"]):
+        assert a.shape == tuple(b.shape)
+        assert np.abs(a - b.numpy()).max() <= 2e-4 * max(1.0, float(b.abs().max()))
+    x4s = m.squeeze_module.forward(parts["x4"].float().numpy())
+    assert np.abs(x4s - parts["x4s"].numpy()).max() <= 2e-4 * max(1.0, float(parts["x4s"].abs().max()))
+    out = m.decoder.forward(x, *[parts[k].float().numpy() for k in ("x1", "x2", "x3", "x4s")])
+    _gate(out, ref.numpy())
+    m.close()

@@ -1,0 +1,169 @@
+"""Op-level parity on the GPU: every C-ABI op entry point against a CPU restatement of the candle op it replaces.
+Tolerances are fp32 reorder noise (the MFMA f32 path is an exact fmaf chain): 2e-5 relative to the output scale."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import torch_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, tol=3e-5):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    scale = max(1.0, float(np.abs(b).max()))
+    err = float(np.abs(a - b).max())
+    assert err <= tol * scale, f"max abs err {err:.3e} > {tol * scale:.3e} (scale {scale:.3g})"
+
+
+def rnd(*shape, seed=0, std=1.0):
+    return (np.random.default_rng(seed).standard_normal(shape) * std).astype(np.float32)
+
+
+@pytest.mark.parametrize("M,K,N", [(300, 192, 576), (1000, 64, 512), (129, 768, 200), (64, 32, 16), (5000, 384, 1536), (7, 96, 130)])
+@pytest.mark.parametrize("act", [None, "gelu_erf", "relu"])
+def test_linear(gpu, M, K, N, act):
+    from candle_birefnet_amd import ops
+    x, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, std=K ** -0.5), rnd(N, seed=3), rnd(M, N, seed=4)
+    y = ops.linear(x, w, b, act=act, residual=r)
+    ref = torch.from_numpy(x).double() @ torch.from_numpy(w).double().T + torch.from_numpy(b).double()
+    if act == "gelu_erf":
+        ref = F.gelu(ref)
+    elif act == "relu":
+        ref = F.relu(ref)
+    ref = ref + torch.from_numpy(r).double()
+    _close(y, ref.numpy())
+
+
+def test_linear_device_tensors(gpu):
+    from candle_birefnet_amd import ops
+    x, w = rnd(512, 192, seed=5), rnd(384, 192, seed=6, std=0.07)
+    xd = torch.from_numpy(x).cuda()
+    y = ops.linear(xd, w)
+    assert y.is_cuda
+    _close(y.cpu().numpy(), x.astype(np.float64) @ w.astype(np.float64).T)
+
+
+@pytest.mark.parametrize("rows,C", [(10, 192), (1000, 384), (33, 768), (5, 1536), (7, 3072), (3, 64)])
+def test_layer_norm(gpu, rows, C):
+    from candle_birefnet_amd import ops
+    x, g, b = rnd(rows, C, seed=1, std=3.0) + 0.5, 1 + rnd(C, seed=2, std=0.1), rnd(C, seed=3, std=0.1)
+    y = ops.layer_norm(x, g, b)
+    ref = F.layer_norm(torch.from_numpy(x).double(), (C,), torch.from_numpy(g).double(), torch.from_numpy(b).double(), 1e-5)
+    _close(y, ref.numpy())
+
+
+@pytest.mark.parametrize("B,C,H,W,O,k,s,p,d", [
+    (2, 64, 16, 16, 256, 3, 1, 1, 1),    # ASPP k3
+    (1, 64, 20, 12, 256, 7, 1, 3, 1),    # ASPP k7
+    (1, 96, 9, 11, 64, 3, 1, 1, 1),      # conv_in-like, ragged map
+    (2, 3, 32, 32, 192, 4, 4, 0, 1),     # PatchEmbed.proj (gather from NCHW)
+    (1, 3, 30, 27, 64, 3, 1, 1, 1),      # ipt_blk1.conv1 (gather), ragged
+    (1, 64, 14, 14, 128, 3, 2, 1, 1),    # strided (DeformableConv2d surface)
+    (1, 64, 24, 24, 256, 3, 1, 6, 6),    # dilated (dead-code ASPP, D2)
+    (2, 128, 8, 8, 48, 1, 1, 0, 1),      # 1x1
+    (1, 48, 8, 8, 64, 3, 1, 1, 1),       # Cin not a multiple of 32 -> gather path
+])
+def test_conv2d(gpu, B, C, H, W, O, k, s, p, d):
+    from candle_birefnet_amd import ops
+    x, w, b = rnd(B, C, H, W, seed=1), rnd(O, C, k, k, seed=2, std=(C * k * k) ** -0.5), rnd(O, seed=3)
+    y = ops.conv2d(x, w, b, stride=s, padding=p, dilation=d)
+    ref = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), stride=s, padding=p, dilation=d)
+    _close(y, ref.numpy())
+
+
+def test_conv2d_bn_relu(gpu):
+    from candle_birefnet_amd import ops
+    B, C, H, W, O = 2, 64, 12, 12, 64
+    x, w, b = rnd(B, C, H, W, seed=1), rnd(O, C, 3, 3, seed=2, std=0.04), rnd(O, seed=3)
+    g, be, m, v = 1 + rnd(O, seed=4, std=0.1), rnd(O, seed=5, std=0.1), rnd(O, seed=6, std=0.1), np.random.default_rng(7).random(O).astype(np.float32) + 0.5
+    y = ops.conv2d(x, w, b, padding=1, bn=(g, be, m, v), act="relu")
+    t = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=1)
+    ref = F.relu(F.batch_norm(t, torch.from_numpy(m).double(), torch.from_numpy(v).double(), torch.from_numpy(g).double(),
+                              torch.from_numpy(be).double(), False, 0.0, 1e-5))
+    _close(y, ref.numpy())
+
+
+@pytest.mark.parametrize("H,W,oh,ow", [(5, 5, 9, 9), (9, 9, 5, 5), (4, 4, 4, 4), (16, 16, 32, 32), (64, 48, 2, 3), (7, 3, 1, 1)])
+def test_upsample_bilinear(gpu, H, W, oh, ow):
+    from candle_birefnet_amd import ops
+    x = rnd(2, 5, H, W, seed=1)
+    y = ops.upsample_bilinear2d(x, oh, ow)
+    ref = F.interpolate(torch.from_numpy(x).double(), size=(oh, ow), mode="bilinear", align_corners=True)
+    _close(y, ref.numpy(), tol=1e-5)
+
+
+def _attn_weights(C, heads, seed):
+    return {"attn.qkv.weight": rnd(3 * C, C, seed=seed, std=C ** -0.5), "attn.qkv.bias": rnd(3 * C, seed=seed + 1, std=0.2),
+            "attn.proj.weight": rnd(C, C, seed=seed + 2, std=C ** -0.5), "attn.proj.bias": rnd(C, seed=seed + 3, std=0.02),
+            "attn.relative_position_bias_table": rnd(529, heads, seed=seed + 4, std=0.5)}
+
+
+@pytest.mark.parametrize("B,H,W,heads,shift", [
+    (1, 12, 12, 2, 0), (1, 12, 12, 2, 6),        # one window
+    (2, 24, 24, 3, 0), (2, 24, 24, 3, 6),        # 4 windows, no padding
+    (1, 16, 16, 2, 0), (1, 16, 16, 2, 6),        # R=16 -> padded to 24 (125 % pad tokens)
+    (1, 32, 20, 6, 6),                           # ragged, Swin-L stage-0 head count
+    (1, 4, 4, 1, 6), (1, 1, 1, 1, 0),            # tiny maps (half-scale stage 3 at small inputs)
+])
+def test_window_attention(gpu, B, H, W, heads, shift):
+    from candle_birefnet_amd import ops
+    C = heads * 32
+    w = _attn_weights(C, heads, seed=10)
+    x = rnd(B, H, W, C, seed=99)
+    y = ops.window_attention(x, heads, shift, w["attn.qkv.weight"], w["attn.qkv.bias"], w["attn.proj.weight"], w["attn.proj.bias"],
+                             w["attn.relative_position_bias_table"])
+    ref = R.window_attention_block(torch.from_numpy(x).double(), w, "", heads, 12, shift, torch.float64)
+    _close(y, ref.numpy())
+
+
+def test_window_attention_swinl_stage_shapes(gpu):
+    """the Swin-L shapes of test_flash_bias.rs:155-158,218-224: stage 0, 484 windows x 6 heads, shifted and not; tolerance
+    there was 0.1 between two GPU paths, here fp32 reorder noise against fp64."""
+    from candle_birefnet_amd import ops
+    heads, C = 6, 192
+    w = _attn_weights(C, heads, seed=20)
+    x = rnd(1, 256, 256, C, seed=7)
+    for shift in (0, 6):
+        y = ops.window_attention(x, heads, shift, w["attn.qkv.weight"], w["attn.qkv.bias"], w["attn.proj.weight"],
+                                 w["attn.proj.bias"], w["attn.relative_position_bias_table"])
+        ref = R.window_attention_block(torch.from_numpy(x), w, "", heads, 12, shift, torch.float32)
+        _close(y, ref.numpy(), tol=1e-4)
+        assert np.abs(y).sum() > 1.0   # "not all zeros" check of test_flash_bias.rs:60-61
+
+
+@pytest.mark.parametrize("B,H,W,C", [(1, 6, 6, 32), (2, 8, 8, 192), (1, 7, 5, 64), (1, 1, 1, 384)])
+def test_patch_merging(gpu, B, H, W, C):
+    from candle_birefnet_amd import ops
+    w = {"norm.weight": 1 + rnd(4 * C, seed=1, std=0.1), "norm.bias": rnd(4 * C, seed=2, std=0.1),
+         "reduction.weight": rnd(2 * C, 4 * C, seed=3, std=(4 * C) ** -0.5)}
+    x = rnd(B, H * W, C, seed=4)
+    y = ops.patch_merging(x, H, W, w["norm.weight"], w["norm.bias"], w["reduction.weight"])
+    ref = R.patch_merging(torch.from_numpy(x).double(), H, W, w, "", torch.float64)
+    _close(y, ref.numpy())
+
+
+@pytest.mark.parametrize("k,stride,pad,O,H", [(3, 1, 1, 128, 32), (1, 1, 0, 256, 8), (7, 1, 3, 256, 12), (3, 2, 1, 64, 16)])
+@pytest.mark.parametrize("mode", ["reference_cpu", "deformable"])
+def test_deform_conv2d(gpu, k, stride, pad, O, H, mode):
+    """test_deform_conv.rs:24-82 (64->128, k3, s1, p1 on [1,64,32,32], shape assertion) + numeric parity in both modes."""
+    import candle_birefnet_amd as cb
+    C = 64
+    t = {"offset_conv.weight": rnd(2 * k * k, C, k, k, seed=1, std=1.5 * (C * k * k) ** -0.5), "offset_conv.bias": rnd(2 * k * k, seed=2, std=0.3),
+         "modulator_conv.weight": rnd(k * k, C, k, k, seed=3, std=(C * k * k) ** -0.5), "modulator_conv.bias": rnd(k * k, seed=4, std=0.1),
+         "regular_conv.weight": rnd(O, C, k, k, seed=5, std=(C * k * k) ** -0.5), "regular_conv.bias": rnd(O, seed=6, std=0.1)}
+    layer = cb.DeformableConv2d.new(C, O, k, stride, pad, cb.VarBuilder.from_tensors(t), mode=mode)
+    x = rnd(1, C, H, H, seed=9)
+    y = layer.forward(x)
+    Ho = (H + 2 * pad - k) // stride + 1
+    assert y.shape == (1, O, Ho, Ho)
+    xt = torch.from_numpy(x).double()
+    td = {n: torch.from_numpy(a).double() for n, a in t.items()}
+    if mode == "reference_cpu":
+        ref = F.conv2d(xt, td["regular_conv.weight"], td["regular_conv.bias"], stride=stride, padding=pad)
+    else:
+        off = F.conv2d(xt, td["offset_conv.weight"], td["offset_conv.bias"], stride=stride, padding=pad)
+        msk = 1.0 / (torch.exp(-F.conv2d(xt, td["modulator_conv.weight"], td["modulator_conv.bias"], stride=stride, padding=pad)) + 1.0) * 2.0
+        ref = R.deform_conv2d(xt, off, msk, td["regular_conv.weight"], td["regular_conv.bias"], stride, pad)
+    _close(y, ref.numpy(), tol=1e-4 if mode == "deformable" else 3e-5)

@@ -1,0 +1,247 @@
+"""Independent second opinion for the oracle: the reference graph written with torch CPU functional ops, straight from
+the Rust sources (file:line cited per function).  Build-owned code — nothing here is imported from /root/reference.
+Runs in fp32 or fp64 (fp64 = the tie-breaker "truth" at small sizes).  Test infrastructure only."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _t(w, name, dtype):
+    return torch.as_tensor(w[name]).to(dtype)
+
+
+def layer_norm(x, w, p, dtype):  # candle_nn::layer_norm(dim, 1e-5) — swin.rs:333
+    return F.layer_norm(x, (x.shape[-1],), _t(w, p + ".weight", dtype), _t(w, p + ".bias", dtype), 1e-5)
+
+
+def linear(x, w, p, dtype, bias=True):  # candle_nn::linear — swin.rs:98-99
+    return F.linear(x, _t(w, p + ".weight", dtype), _t(w, p + ".bias", dtype) if bias else None)
+
+
+def conv(x, w, p, dtype, pad=0, stride=1, bias=True):  # candle_nn::conv2d
+    return F.conv2d(x, _t(w, p + ".weight", dtype), _t(w, p + ".bias", dtype) if bias else None, stride=stride, padding=pad)
+
+
+def bn(x, w, p, dtype):  # candle_nn::batch_norm(.., 1e-5).forward_t(x, false) — decoder.rs:105,129
+    return F.batch_norm(x, _t(w, p + ".running_mean", dtype), _t(w, p + ".running_var", dtype), _t(w, p + ".weight", dtype),
+                        _t(w, p + ".bias", dtype), False, 0.0, 1e-5)
+
+
+def up(x, h, wd):  # upsample_bilinear2d(h, w, align_corners=true) — birefnet.rs:332
+    return F.interpolate(x, size=(h, wd), mode="bilinear", align_corners=True)
+
+
+# ---- Swin (swin.rs) ---------------------------------------------------------------------------------------------------
+def rel_index(ws):  # swin.rs:166-210
+    idx = torch.empty(ws * ws, ws * ws, dtype=torch.long)
+    for i in range(ws):
+        for j in range(ws):
+            for k in range(ws):
+                for l in range(ws):
+                    idx[i * ws + j, k * ws + l] = (i - k + ws - 1) * (2 * ws - 1) + (j - l + ws - 1)
+    return idx
+
+
+_REL = {}
+
+
+def attn_mask(hp, wp, ws, shift, dtype):  # swin.rs:603-655
+    img = torch.zeros(hp, wp, dtype=dtype)
+    cnt = 0
+    for hs, he in ((0, hp - ws), (hp - ws, hp - shift), (hp - shift, hp)):
+        for wss, we in ((0, wp - ws), (wp - ws, wp - shift), (wp - shift, wp)):
+            img[hs:he, wss:we] = cnt
+            cnt += 1
+    m = img.reshape(hp // ws, ws, wp // ws, ws).permute(0, 2, 1, 3).reshape(-1, ws * ws)
+    d = m.unsqueeze(1) - m.unsqueeze(2)
+    return torch.where(d != 0, torch.full_like(d, -100.0), torch.zeros_like(d))
+
+
+def window_attention_block(xn, w, p, heads, ws, shift, dtype, mask=None):
+    """swin.rs:356-403 + 212-312: xn [B,H,W,C] (norm1 output) -> attention output [B,H,W,C] (before the residual)."""
+    B, H, W, C = xn.shape
+    pad_r, pad_b = (ws - W % ws) % ws, (ws - H % ws) % ws
+    x = F.pad(xn, (0, 0, 0, pad_r, 0, pad_b))
+    hp, wp = x.shape[1], x.shape[2]
+    if shift > 0:
+        x = torch.roll(x, shifts=(-shift, -shift), dims=(1, 2))
+    xw = x.reshape(B, hp // ws, ws, wp // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C)
+    b_, n, _ = xw.shape
+    hd = C // heads
+    qkv = linear(xw, w, p + "attn.qkv", dtype).reshape(b_, n, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    q = q * (hd ** -0.5)
+    attn = q @ k.transpose(-2, -1)
+    if ws not in _REL:
+        _REL[ws] = rel_index(ws)
+    table = _t(w, p + "attn.relative_position_bias_table", dtype)
+    bias = table[_REL[ws].reshape(-1)].reshape(n, n, heads).permute(2, 0, 1)
+    attn = attn + bias.unsqueeze(0)
+    if shift > 0:
+        if mask is None:
+            mask = attn_mask(hp, wp, ws, shift, dtype)
+        nW = mask.shape[0]
+        attn = (attn.reshape(b_ // nW, nW, heads, n, n) + mask.unsqueeze(0).unsqueeze(2)).reshape(b_, heads, n, n)
+    attn = torch.softmax(attn, dim=-1)
+    o = (attn @ v).transpose(1, 2).reshape(b_, n, C)
+    o = linear(o, w, p + "attn.proj", dtype)
+    o = o.reshape(B, hp // ws, wp // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, hp, wp, C)
+    if shift > 0:
+        o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
+    return o[:, :H, :W, :]
+
+
+def swin_block(x, H, W, w, p, heads, ws, shift, dtype):  # swin.rs:350-410
+    B, L, C = x.shape
+    assert L == H * W
+    xn = layer_norm(x, w, p + "norm1", dtype).reshape(B, H, W, C)
+    a = window_attention_block(xn, w, p, heads, ws, shift, dtype).reshape(B, H * W, C)
+    x = x + a
+    h = layer_norm(x, w, p + "norm2", dtype)
+    h = F.gelu(linear(h, w, p + "mlp.fc1", dtype))  # exact erf GELU, swin.rs:105
+    return x + linear(h, w, p + "mlp.fc2", dtype)
+
+
+def patch_merging(x, H, W, w, p, dtype):  # swin.rs:491-527
+    B, _, C = x.shape
+    x = x.reshape(B, H, W, C)
+    if H % 2 or W % 2:
+        x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+    x0, x1, x2, x3 = x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]
+    x = torch.cat([x0, x1, x2, x3], -1)
+    x = x.reshape(B, -1, 4 * C)
+    x = layer_norm(x, w, p + "norm", dtype)
+    return linear(x, w, p + "reduction", dtype, bias=False)
+
+
+def swin_forward(x, w, cfg, prefix="", dtype=torch.float32):  # swin.rs:768-797
+    P, ws = cfg.patch_size, cfg.window_size
+    _, _, H, W = x.shape
+    if H % P or W % P:
+        x = F.pad(x, (0, (P - W % P) % P, 0, (P - H % P) % P))
+    x = conv(x, w, prefix + "patch_embed.proj", dtype, stride=P)
+    B, C, h, wd = x.shape
+    x = layer_norm(x.flatten(2).transpose(1, 2), w, prefix + "patch_embed.norm", dtype)
+    outs = []
+    for i, depth in enumerate(cfg.depths):
+        heads = cfg.num_heads[i]
+        for j in range(depth):
+            x = swin_block(x, h, wd, w, f"{prefix}layers.{i}.blocks.{j}.", heads, ws, 0 if j % 2 == 0 else ws // 2, dtype)
+        Ci = cfg.embed_dim << i
+        outs.append(layer_norm(x, w, f"{prefix}norm{i}", dtype).reshape(B, h, wd, Ci).permute(0, 3, 1, 2))
+        if i < len(cfg.depths) - 1:
+            x = patch_merging(x, h, wd, w, f"{prefix}layers.{i}.downsample.", dtype)
+            h, wd = (h + 1) // 2, (wd + 1) // 2
+    return outs
+
+
+# ---- deformable conv (torchvision.ops.deform_conv2d semantics, written out) -----------------------------------
+def deform_conv2d(x, offset, mask, weight, bias, stride, pad):
+    B, C, H, W = x.shape
+    O, _, kh, kw = weight.shape
+    Ho, Wo = offset.shape[2], offset.shape[3]
+    ys = torch.arange(Ho, dtype=x.dtype).view(1, Ho, 1) * stride - pad
+    xs = torch.arange(Wo, dtype=x.dtype).view(1, 1, Wo) * stride - pad
+    cols = []
+    for i in range(kh):
+        for j in range(kw):
+            t = i * kw + j
+            py = ys + i + offset[:, 2 * t]
+            px = xs + j + offset[:, 2 * t + 1]
+            valid = (py > -1) & (py < H) & (px > -1) & (px < W)
+            y0, x0 = torch.floor(py), torch.floor(px)
+            ly, lx = py - y0, px - x0
+            val = torch.zeros(B, C, Ho, Wo, dtype=x.dtype)
+            for dy, wy in ((0, 1 - ly), (1, ly)):
+                for dx, wx in ((0, 1 - lx), (1, lx)):
+                    yy, xx = (y0 + dy).long(), (x0 + dx).long()
+                    ok = valid & (yy >= 0) & (yy <= H - 1) & (xx >= 0) & (xx <= W - 1)
+                    idx = (yy.clamp(0, H - 1) * W + xx.clamp(0, W - 1)).view(B, 1, -1).expand(B, C, -1)
+                    g = torch.gather(x.reshape(B, C, H * W), 2, idx).view(B, C, Ho, Wo)
+                    val = val + g * (wy * wx * ok.to(x.dtype)).unsqueeze(1)
+            cols.append(val * mask[:, t].unsqueeze(1))
+    col = torch.stack(cols, 2)  # [B, C, kh*kw, Ho, Wo]
+    out = torch.einsum("bckhw,ock->bohw", col, weight.reshape(O, C, kh * kw))
+    if bias is not None:
+        out = out + bias.view(1, -1, 1, 1)
+    return out
+
+
+def deform_conv_aspp(x, w, p, k, dtype, mode):  # DeformConvASPP::forward — aspp.rs:168-187
+    pad = k // 2
+    if mode == "reference_cpu":
+        return conv(x, w, p + "regular_conv", dtype, pad=pad, bias=False)  # aspp.rs:183-185
+    offset = conv(x, w, p + "offset_conv", dtype, pad=pad)
+    mask = 1.0 / (torch.exp(-conv(x, w, p + "modulator_conv", dtype, pad=pad)) + 1.0) * 2.0  # aspp.rs:173-174
+    return deform_conv2d(x, offset, mask, _t(w, p + "regular_conv.weight", dtype), None, 1, pad)
+
+
+# ---- decoder pieces ---------------------------------------------------------------------------------------------------------
+def aspp_deformable(x, w, p, dtype, mode):  # aspp.rs:303-333
+    def module(q, k):
+        return F.relu(bn(deform_conv_aspp(x, w, q + "atrous_conv.", k, dtype, mode), w, q + "bn", dtype))
+    outs = [module(p + "aspp1.", 1)] + [module(f"{p}aspp_deforms.{i}.", k) for i, k in enumerate((1, 3, 7))]
+    _, _, H, W = x.shape
+    g = x.mean(dim=2, keepdim=True).mean(dim=3, keepdim=True)
+    g = F.relu(bn(conv(g, w, p + "global_avg_pool.1", dtype, bias=False), w, p + "global_avg_pool.2", dtype))
+    outs.append(g.expand(-1, -1, H, W))
+    o = conv(torch.cat(outs, 1), w, p + "conv1", dtype, bias=False)
+    return F.relu(bn(o, w, p + "bn1", dtype))
+
+
+def dec_blk(x, w, p, dtype, mode):  # decoder.rs:126-141
+    x = F.relu(bn(conv(x, w, p + "conv_in", dtype, pad=1), w, p + "bn_in", dtype))
+    x = aspp_deformable(x, w, p + "dec_att.", dtype, mode)
+    return bn(conv(x, w, p + "conv_out", dtype, pad=1), w, p + "bn_out", dtype)
+
+
+def simple_convs(x, w, p, dtype):  # decoder.rs:50-56 (no activation in between)
+    return conv(conv(x, w, p + "conv1", dtype, pad=1), w, p + "conv_out", dtype, pad=1)
+
+
+def image2patches(x, th, tw):  # birefnet.rs:288-300
+    b, c, h, w = x.shape
+    gh, gw = h // th, w // tw
+    return x.reshape(b, c, gh, th, gw, tw).permute(0, 1, 2, 4, 3, 5).reshape(b, c * gh * gw, th, tw)
+
+
+def decoder_forward(x, x1, x2, x3, x4, w, dtype, mode, p="decoder."):  # birefnet.rs:278-376
+    _, _, H, W = x.shape
+    h3, w3, h2, w2, h1, w1 = x3.shape[2], x3.shape[3], x2.shape[2], x2.shape[3], x1.shape[2], x1.shape[3]
+    ipt5 = simple_convs(image2patches(x, H // 32, W // 32), w, p + "ipt_blk5.", dtype)
+    ipt4 = simple_convs(image2patches(x, H // 16, W // 16), w, p + "ipt_blk4.", dtype)
+    ipt3 = simple_convs(image2patches(x, H // 8, W // 8), w, p + "ipt_blk3.", dtype)
+    ipt2 = simple_convs(image2patches(x, H // 4, W // 4), w, p + "ipt_blk2.", dtype)
+    ipt1 = simple_convs(x, w, p + "ipt_blk1.", dtype)
+
+    def gate(pp, n):
+        g = F.relu(bn(conv(pp, w, f"{p}gdt_convs_{n}.0", dtype, pad=1), w, f"{p}gdt_convs_{n}.1", dtype))
+        return pp * torch.sigmoid(conv(g, w, f"{p}gdt_convs_attn_{n}.0", dtype))
+
+    p4 = gate(dec_blk(torch.cat([x4, ipt5], 1), w, p + "decoder_block4.", dtype, mode), 4)
+    p3_in = up(p4, h3, w3) + conv(x3, w, p + "lateral_block4.conv", dtype)
+    p3 = gate(dec_blk(torch.cat([p3_in, up(ipt4, h3, w3)], 1), w, p + "decoder_block3.", dtype, mode), 3)
+    p2_in = up(p3, h2, w2) + conv(x2, w, p + "lateral_block3.conv", dtype)
+    p2 = gate(dec_blk(torch.cat([p2_in, up(ipt3, h2, w2)], 1), w, p + "decoder_block2.", dtype, mode), 2)
+    p1_in = up(p2, h1, w1) + conv(x1, w, p + "lateral_block2.conv", dtype)
+    p1 = dec_blk(torch.cat([p1_in, up(ipt2, h1, w1)], 1), w, p + "decoder_block1.", dtype, mode)
+    final_in = torch.cat([up(p1, H, W), up(ipt1, H, W)], 1)
+    return conv(final_in, w, p + "conv_out1.0", dtype)
+
+
+def forward_logits(x, w, cfg, dtype=torch.float32, return_parts=False):  # birefnet.rs:412-461
+    x = torch.as_tensor(x).to(dtype)
+    mode = cfg.deform_mode
+    _, _, H, W = x.shape
+    f = swin_forward(x, w, cfg.swin, "bb.", dtype)
+    fh = swin_forward(up(x, H // 2, W // 2), w, cfg.swin, "bb.", dtype)
+    xs = [torch.cat([a, up(b, a.shape[2], a.shape[3])], 1) for a, b in zip(f, fh)]
+    x1, x2, x3, x4 = xs
+    h4, w4 = x4.shape[2], x4.shape[3]
+    x4 = torch.cat([up(x1, h4, w4), up(x2, h4, w4), up(x3, h4, w4), x4], 1)
+    x4s = dec_blk(x4, w, "squeeze_module.0.", dtype, mode)
+    out = decoder_forward(x, x1, x2, x3, x4s, w, dtype, mode)
+    if return_parts:
+        return out, dict(f=f, fh=fh, x1=x1, x2=x2, x3=x3, x4=x4, x4s=x4s)
+    return out
