@@ -6,6 +6,7 @@
 #include <cmath>
 #include <functional>
 #include <memory>
+#include <cstdlib>
 
 namespace brn {
 const char* last_error_cstr();
@@ -110,11 +111,17 @@ static void plan_model(Model& m, int B, int H, int W) {
 static void collect_profile(Model& m, hipStream_t s) {
     BRN_HIP(hipStreamSynchronize(s));
     for (int f = 0; f < FAM_COUNT; ++f) { m.fam_launches[f] = 0; m.fam_ms[f] = 0.f; m.fam_flop[f] = 0.0; m.fam_bytes[f] = 0.0; }
+    // BRN_DUMP_LAUNCHES=<path>: one CSV row per launch of the last profiled forward (tuning aid)
+    const char* dump = getenv("BRN_DUMP_LAUNCHES");
+    FILE* df = dump ? fopen(dump, "w") : nullptr;
+    if (df) fprintf(df, "family,M,N,K,ms,gflop,tflops\n");
     for (auto& r : m.records) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) ms = 0.f;
+        if (df) fprintf(df, "%s,%d,%d,%d,%.4f,%.3f,%.2f\n", brn_kernel_family_name(r.fam), r.M, r.N, r.K, ms, r.flop / 1e9, ms > 0 ? r.flop / ms / 1e9 : 0.0);
         m.fam_launches[r.fam]++; m.fam_ms[r.fam] += ms; m.fam_flop[r.fam] += r.flop; m.fam_bytes[r.fam] += r.bytes;
     }
+    if (df) fclose(df);
     if (m.stage_ev_ok) {
         for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&m.last_ms[i], m.stage_ev[i], m.stage_ev[i + 1]);
         (void)hipEventElapsedTime(&m.last_ms[4], m.stage_ev[0], m.stage_ev[4]);

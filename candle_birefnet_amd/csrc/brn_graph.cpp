@@ -31,7 +31,7 @@ Map new_map(Ctx& c, int B, int H, int W, int C) {
 // ---- launch bracket -----------------------------------------------------------------------------------------------
 struct Bracket {
     Ctx& c; bool on;
-    Bracket(Ctx& c_, int fam, double flop, double bytes) : c(c_), on(c_.profile && !c_.dry) {
+    Bracket(Ctx& c_, int fam, double flop, double bytes, int M = 0, int N = 0, int K = 0) : c(c_), on(c_.profile && !c_.dry) {
         if (!on) return;
         auto next = [&]() -> hipEvent_t {
             if (*c.event_next >= c.event_pool->size()) {
@@ -39,7 +39,7 @@ struct Bracket {
             }
             return (*c.event_pool)[(*c.event_next)++];
         };
-        LaunchRecord r; r.fam = fam; r.flop = flop; r.bytes = bytes; r.e0 = next(); r.e1 = next();
+        LaunchRecord r; r.fam = fam; r.flop = flop; r.bytes = bytes; r.e0 = next(); r.e1 = next(); r.M = M; r.N = N; r.K = K;
         BRN_HIP(hipEventRecord(r.e0, c.stream));
         c.records->push_back(r);
     }
@@ -66,7 +66,7 @@ void run_gemm(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* C, 
     p.R = R; p.ldr = ldr; p.r_coff = r_coff; p.ldc = ldc; p.c_coff = c_coff;
     const double flop = 2.0 * M * (double)w.N * w.K;
     const double bytes = 4.0 * ((double)M * w.K + (double)w.N * w.K + (double)M * w.N * (R ? 2 : 1));
-    Bracket b(c, FAM_GEMM_DENSE, flop, bytes);
+    Bracket b(c, FAM_GEMM_DENSE, flop, bytes, M, w.N, w.K);
     BRN_LAUNCH(launch_gemm(p, c.stream));
 }
 
@@ -95,7 +95,7 @@ void run_conv(Ctx& c, const GemmW& w, const Map& in, const Map& out, const float
     if (w.mode == GEMM_DEFORM_NHWC && !om) fail(BRN_ERR_INVALID_ARG, "deformable conv without an offset/modulator map");
     const double flop = 2.0 * M * (double)w.N * w.K;
     const double bytes = 4.0 * ((double)in.pixels() * w.Cinp + (double)w.N * w.K + (double)M * w.N);
-    Bracket b(c, w.mode == GEMM_DEFORM_NHWC ? FAM_GEMM_DEFORM : FAM_GEMM_CONV, flop, bytes);
+    Bracket b(c, w.mode == GEMM_DEFORM_NHWC ? FAM_GEMM_DEFORM : FAM_GEMM_CONV, flop, bytes, M, w.N, w.K);
     BRN_LAUNCH(launch_gemm(p, c.stream));
 }
 
@@ -114,7 +114,7 @@ void run_conv_nchw(Ctx& c, const GemmW& w, const float* x, int B, int Hin, int W
     p.bbias_rows = 1; p.ldc = out.ld; p.c_coff = out.coff;
     const double flop = 2.0 * M * (double)w.N * w.Kreal;
     const double bytes = 4.0 * ((double)B * w.Cin * Hin * Win + (double)w.N * w.K + (double)M * w.N);
-    Bracket b(c, FAM_GEMM_GATHER, flop, bytes);
+    Bracket b(c, FAM_GEMM_GATHER, flop, bytes, M, w.N, w.K);
     BRN_LAUNCH(launch_gemm(p, c.stream));
 }
 
@@ -157,7 +157,7 @@ void swin_attention(Ctx& c, const SwinBlockW& blk, const float* xn, int B, int H
         p.Hp = roundup(H, 12); p.Wp = roundup(W, 12);                // swin.rs:359-360
         p.shift = shift; p.scale = 1.0f / sqrtf(32.0f);              // head_dim^-0.5 (swin.rs:134)
         const double nwin = (double)B * (p.Hp / 12) * (p.Wp / 12) * blk.heads;
-        Bracket b(c, FAM_ATTENTION, nwin * 2.0 * 2.0 * 144 * 144 * 32, 4.0 * ((double)M * 4 * C));
+        Bracket b(c, FAM_ATTENTION, nwin * 2.0 * 2.0 * 144 * 144 * 32, 4.0 * ((double)M * 4 * C), M, C, shift);
         BRN_LAUNCH(launch_window_attention(p, c.stream));
     }
     run_gemm(c, blk.proj, att, M, C, y, C, 0, residual, C, 0);      // swin.rs:310 (+ shortcut, swin.rs:406)
@@ -252,9 +252,10 @@ void decblk_forward(Ctx& c, const DecBlkW& w, const Map& in, const Map& out, int
     float* g0 = c.arena->alloc((size_t)B * 64);
     float* g1 = c.arena->alloc((size_t)B * 256);
     float* gb = c.arena->alloc((size_t)B * 64);
+    float* gscr = c.arena->alloc(gap_scratch_floats(B, H * W, 64));
     if (!c.dry) {
         Bracket b(c, FAM_ELEMENTWISE, 0.0, 4.0 * M * 64);
-        BRN_LAUNCH(launch_gap_nhwc(t.p, B, H * W, 64, 64, 0, g0, c.stream));
+        BRN_LAUNCH(launch_gap_nhwc(t.p, B, H * W, 64, 64, 0, gscr, g0, c.stream));
         BRN_LAUNCH(launch_small_fc(g0, B, 64, a.gap_w, 64, 0, 256, a.gap_scale, a.gap_shift, ACT_RELU, g1, c.stream));
         BRN_LAUNCH(launch_small_fc(g1, B, 256, a.conv1_full, 1280, 1024, 64, nullptr, nullptr, ACT_NONE, gb, c.stream));
     }

@@ -32,7 +32,7 @@ enum Family {
     FAM_RESIZE, FAM_ELEMENTWISE, FAM_COUNT
 };
 
-struct LaunchRecord { int fam; double flop; double bytes; hipEvent_t e0, e1; };
+struct LaunchRecord { int fam; double flop; double bytes; hipEvent_t e0, e1; int M, N, K; };
 
 // ---- HBM arena: one allocation, stack discipline (mark / release) ------------------------------------------
 // In dry-run mode nothing is allocated or launched: the same graph code walks the plan and records the peak.

@@ -79,7 +79,8 @@ hipError_t launch_nhwc_to_nchw(const float* x, int B, int C, int H, int W, int l
 hipError_t launch_image2patches(const float* x, int B, int Cimg, int H, int W, int th, int tw,
                                 float* y, int ldy, int cpad, hipStream_t s);
 // per-(b,c) mean over H*W of a channels-last window: out[b][c]   (aspp.rs:314)
-hipError_t launch_gap_nhwc(const float* x, int B, int HW, int C, int ldx, int x_coff, float* out, hipStream_t s);
+size_t gap_scratch_floats(int B, int HW, int C);
+hipError_t launch_gap_nhwc(const float* x, int B, int HW, int C, int ldx, int x_coff, float* scratch, float* out, hipStream_t s);
 // tiny dense layers on [B,Cin] vectors: y[b][n] = act((sum_k x[b][k] w[n*ldw + w_off + k]) * scale[n] + shift[n])
 hipError_t launch_small_fc(const float* x, int B, int Cin, const float* w, int ldw, int w_off, int N,
                            const float* scale, const float* shift, int act, float* y, hipStream_t s);

@@ -156,20 +156,34 @@ hipError_t launch_image2patches(const float* x, int B, int Cimg, int H, int W, i
     return hipGetLastError();
 }
 
-// x.mean_keepdim(H).mean_keepdim(W) (aspp.rs:314) on a channels-last window: one block per (b, 64-channel group)
-__global__ void gap_nhwc_kernel(const float* __restrict__ x, int HW, int C, int ldx, int x_coff, float* __restrict__ out) {
+// x.mean_keepdim(H).mean_keepdim(W) (aspp.rs:314) on a channels-last window.  Two deterministic passes (no float
+// atomics: replicas on different GPUs must agree bit for bit): per-chunk partial sums, then a fixed-order final sum.
+constexpr int GAP_CHUNK = 512;   // pixels per block of pass 1
+__global__ void gap_partial_kernel(const float* __restrict__ x, int HW, int C, int ldx, int x_coff, float* __restrict__ part) {
     __shared__ float red[4][64];
-    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    const int b = blockIdx.z, chunk = blockIdx.y, nchunks = gridDim.y;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+    const int p0 = chunk * GAP_CHUNK, p1 = min(HW, p0 + GAP_CHUNK);
     float acc = 0.f;
     if (c < C)
-        for (int pq = part; pq < HW; pq += 4) acc += x[((size_t)b * HW + pq) * ldx + x_coff + c];
-    red[part][threadIdx.x & 63] = acc;
+        for (int pq = p0 + sub; pq < p1; pq += 4) acc += x[((size_t)b * HW + pq) * ldx + x_coff + c];
+    red[sub][threadIdx.x & 63] = acc;
     __syncthreads();
-    if (part == 0 && c < C) out[(size_t)b * C + c] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) / (float)HW;
+    if (sub == 0 && c < C)
+        part[((size_t)b * nchunks + chunk) * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-hipError_t launch_gap_nhwc(const float* x, int B, int HW, int C, int ldx, int x_coff, float* out, hipStream_t s) {
-    dim3 grid((C + 63) / 64, B);
-    hipLaunchKernelGGL(gap_nhwc_kernel, grid, dim3(256), 0, s, x, HW, C, ldx, x_coff, out);
+__global__ void gap_final_kernel(const float* __restrict__ part, int nchunks, int C, int HW, float* __restrict__ out) {
+    const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float acc = 0.f;
+    for (int k = 0; k < nchunks; ++k) acc += part[((size_t)b * nchunks + k) * C + c];
+    out[(size_t)b * C + c] = acc / (float)HW;
+}
+size_t gap_scratch_floats(int B, int HW, int C) { return (size_t)B * ((HW + GAP_CHUNK - 1) / GAP_CHUNK) * C; }
+hipError_t launch_gap_nhwc(const float* x, int B, int HW, int C, int ldx, int x_coff, float* scratch, float* out, hipStream_t s) {
+    const int nchunks = (HW + GAP_CHUNK - 1) / GAP_CHUNK;
+    hipLaunchKernelGGL(gap_partial_kernel, dim3((C + 63) / 64, nchunks, B), dim3(256), 0, s, x, HW, C, ldx, x_coff, scratch);
+    hipLaunchKernelGGL(gap_final_kernel, dim3((C + 63) / 64, B), dim3(64), 0, s, scratch, nchunks, C, HW, out);
     return hipGetLastError();
 }
 
