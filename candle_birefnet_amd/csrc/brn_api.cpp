@@ -510,16 +510,7 @@ brn_status brn_window_attention_forward(const float* x, int B, int H, int W, int
         bk.qkv = make_linear(own, qkv_w, qkv_b, 3 * C, C);
         bk.proj = make_linear(own, proj_w, proj_b, C, C);
         (void)s_qw; (void)s_qb; (void)s_pw; (void)s_pb; (void)s_t;
-        {
-            const int ws = 12, N = 144;
-            std::vector<float> bt((size_t)heads * N * N);
-            for (int q = 0; q < N; ++q)
-                for (int k = 0; k < N; ++k) {
-                    const int idx = (q / ws - k / ws + ws - 1) * (2 * ws - 1) + (q % ws - k % ws + ws - 1);
-                    for (int h = 0; h < heads; ++h) bt[((size_t)h * N + k) * N + q] = rel_table[(size_t)idx * heads + h];
-                }
-            bk.biasT = own.upload(bt);
-        }
+        bk.rel_table = own.upload(rel_table, (size_t)T * heads);
         Staging st(stream, loc);
         const float* dx = st.in(x, (size_t)B * H * W * C);
         float* dy = st.out(y, (size_t)B * H * W * C);
@@ -597,6 +588,41 @@ brn_status brn_deform_conv2d_forward(const float* x, int B, int C, int H, int W,
             if (!c.dry) BRN_HIP(launch_nhwc_to_nchw(Y.p, B, O, Ho, Wo, Y.ld, 0, dy, c.stream));
         });
         st.finish();
+    });
+}
+
+// ---- diagnostics -----------------------------------------------------------------------------------------------------
+brn_status brn_gemm_microbench(int M, int N, int K, int tile_cfg, int splitk, int iters, int device, float* ms_per_launch) {
+    return guarded([&] {
+        if (M < 1 || N < 1 || K < 32 || K % 32 || iters < 1 || !ms_per_launch) fail(BRN_ERR_INVALID_ARG, "bad argument");
+        ensure_device(device);
+        DeviceOwner own;
+        std::vector<float> ha((size_t)M * K), hw((size_t)((N + 127) / 128 * 128) * K, 0.f);
+        uint32_t s = 12345u;
+        auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xFFFF) / 32768.0f - 1.0f; };
+        for (auto& v : ha) v = rnd();
+        for (size_t i = 0; i < (size_t)N * K; ++i) hw[i] = rnd();
+        float* dA = own.upload(ha);
+        float* dW = own.upload(hw);
+        std::vector<float> hc((size_t)M * N, 0.f);
+        float* dC = own.upload(hc);
+        GemmPlan pl = plan_gemm(M, N, K);
+        if (tile_cfg >= 0) { pl.cfg = tile_cfg; pl.splitk = splitk > 1 ? splitk : 1; pl.ws_floats = pl.splitk > 1 ? (size_t)pl.splitk * M * N : 0; }
+        float* ws = nullptr;
+        if (pl.ws_floats) { std::vector<float> z(pl.ws_floats, 0.f); ws = own.upload(z); }
+        GemmParams p{};
+        p.A = dA; p.W = dW; p.C = dC; p.M = M; p.N = N; p.K = K; p.mode = GEMM_DENSE; p.lda = K; p.ldc = N; p.bbias_rows = 1;
+        hipEvent_t e0, e1;
+        BRN_HIP(hipEventCreate(&e0)); BRN_HIP(hipEventCreate(&e1));
+        for (int i = 0; i < 3; ++i) BRN_HIP(launch_gemm(p, pl, ws, nullptr));
+        BRN_HIP(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < iters; ++i) BRN_HIP(launch_gemm(p, pl, ws, nullptr));
+        BRN_HIP(hipEventRecord(e1, nullptr));
+        BRN_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        BRN_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        *ms_per_launch = ms / iters;
     });
 }
 

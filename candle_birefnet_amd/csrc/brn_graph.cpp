@@ -58,6 +58,10 @@ static void fill_epilogue(GemmParams& p, const GemmW& w) {
 
 void run_gemm(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* C, int ldc, int c_coff, const float* R, int ldr,
               int r_coff, const float* bbias, int bbias_rows) {
+    const GemmPlan pl = plan_gemm(M, w.N, w.K);
+    const size_t mk = c.arena->mark();
+    float* ws = pl.ws_floats ? c.arena->alloc(pl.ws_floats) : nullptr;
+    c.arena->release(mk);          // scratch is dead as soon as the reduce pass has been enqueued (in-order stream)
     if (c.dry) return;
     GemmParams p{};
     p.A = A; p.W = w.w; p.C = C; p.M = M; p.N = w.N; p.K = w.K; p.mode = GEMM_DENSE; p.lda = lda;
@@ -67,7 +71,7 @@ void run_gemm(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* C, 
     const double flop = 2.0 * M * (double)w.N * w.K;
     const double bytes = 4.0 * ((double)M * w.K + (double)w.N * w.K + (double)M * w.N * (R ? 2 : 1));
     Bracket b(c, FAM_GEMM_DENSE, flop, bytes, M, w.N, w.K);
-    BRN_LAUNCH(launch_gemm(p, c.stream));
+    BRN_LAUNCH(launch_gemm(p, pl, ws, c.stream));
 }
 
 void run_conv(Ctx& c, const GemmW& w, const Map& in, const Map& out, const float* om, int om_ld, int om_mask_off) {
@@ -83,6 +87,10 @@ void run_conv(Ctx& c, const GemmW& w, const Map& in, const Map& out, const float
         run_gemm(c, w, in.p + in.coff, M, in.ld, out.p, out.ld, out.coff);
         return;
     }
+    const GemmPlan pl = plan_gemm(M, w.N, w.K);
+    const size_t mk = c.arena->mark();
+    float* ws = pl.ws_floats ? c.arena->alloc(pl.ws_floats) : nullptr;
+    c.arena->release(mk);
     if (c.dry) return;
     GemmParams p{};
     p.A = in.p; p.W = w.w; p.C = out.p; p.M = M; p.N = w.N; p.K = w.K; p.mode = w.mode;
@@ -96,7 +104,7 @@ void run_conv(Ctx& c, const GemmW& w, const Map& in, const Map& out, const float
     const double flop = 2.0 * M * (double)w.N * w.K;
     const double bytes = 4.0 * ((double)in.pixels() * w.Cinp + (double)w.N * w.K + (double)M * w.N);
     Bracket b(c, w.mode == GEMM_DEFORM_NHWC ? FAM_GEMM_DEFORM : FAM_GEMM_CONV, flop, bytes, M, w.N, w.K);
-    BRN_LAUNCH(launch_gemm(p, c.stream));
+    BRN_LAUNCH(launch_gemm(p, pl, ws, c.stream));
 }
 
 void run_conv_nchw(Ctx& c, const GemmW& w, const float* x, int B, int Hin, int Win, const Map& out) {
@@ -104,8 +112,12 @@ void run_conv_nchw(Ctx& c, const GemmW& w, const float* x, int B, int Hin, int W
     const int Wout = (Win + 2 * w.pad - w.dil * (w.kw - 1) - 1) / w.stride + 1;
     if (out.H != Hout || out.W != Wout || out.B != B || out.C != w.N)
         fail(BRN_ERR_INVALID_ARG, "conv(nchw) output map mismatch");
-    if (c.dry) return;
     const int M = B * Hout * Wout;
+    const GemmPlan pl = plan_gemm(M, w.N, w.K);
+    const size_t mk = c.arena->mark();
+    float* ws = pl.ws_floats ? c.arena->alloc(pl.ws_floats) : nullptr;
+    c.arena->release(mk);
+    if (c.dry) return;
     GemmParams p{};
     p.A = x; p.W = w.w; p.C = out.p; p.M = M; p.N = w.N; p.K = w.K; p.mode = GEMM_GATHER_NCHW;
     p.Hin = Hin; p.Win = Win; p.Cin = w.Cin; p.kh = w.kh; p.kw = w.kw; p.stride = w.stride; p.pad = w.pad; p.dil = w.dil;
@@ -115,7 +127,7 @@ void run_conv_nchw(Ctx& c, const GemmW& w, const float* x, int B, int Hin, int W
     const double flop = 2.0 * M * (double)w.N * w.Kreal;
     const double bytes = 4.0 * ((double)B * w.Cin * Hin * Win + (double)w.N * w.K + (double)M * w.N);
     Bracket b(c, FAM_GEMM_GATHER, flop, bytes, M, w.N, w.K);
-    BRN_LAUNCH(launch_gemm(p, c.stream));
+    BRN_LAUNCH(launch_gemm(p, pl, ws, c.stream));
 }
 
 void run_layernorm(Ctx& c, const LNW& ln, const float* x, int rows, int ldx, float* y, int ldy, int y_coff) {
@@ -152,7 +164,7 @@ void swin_attention(Ctx& c, const SwinBlockW& blk, const float* xn, int B, int H
     run_gemm(c, blk.qkv, xn, M, C, qkv, 3 * C, 0);                   // swin.rs:217 (pad rows are synthesised by the kernel)
     if (!c.dry) {
         WindowAttnParams p{};
-        p.qkv = qkv; p.qkv_bias = blk.qkv.bias; p.biasT = blk.biasT; p.out = att;
+        p.qkv = qkv; p.qkv_bias = blk.qkv.bias; p.rel_table = blk.rel_table; p.out = att;
         p.B = B; p.H = H; p.W = W; p.C = C; p.heads = blk.heads;
         p.Hp = roundup(H, 12); p.Wp = roundup(W, 12);                // swin.rs:359-360
         p.shift = shift; p.scale = 1.0f / sqrtf(32.0f);              // head_dim^-0.5 (swin.rs:134)

@@ -81,7 +81,7 @@ struct LNW { float* g = nullptr; float* b = nullptr; int C = 0; };
 struct SwinBlockW {
     LNW norm1, norm2;
     GemmW qkv, proj, fc1, fc2;
-    float* biasT = nullptr;   // [heads][144][144]
+    float* rel_table = nullptr;   // [529][heads], as stored
     int heads = 0;
 };
 struct SwinStageW {

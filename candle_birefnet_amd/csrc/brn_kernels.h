@@ -37,10 +37,14 @@ struct GemmParams {
     int act;
     const float* R; int ldr; int r_coff;
     int ldc; int c_coff;
+    // split-K (filled by launch_gemm from the plan): slices write raw partials to part[slice][M][N]
+    int splitk; float* part;
 };
 
-// returns hipError_t of the launch
-hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
+struct GemmPlan { int cfg; int splitk; size_t ws_floats; };   // cfg: 0 = 128x128, 1 = 128x64, 2 = 64x64 block tile
+GemmPlan plan_gemm(int M, int N, int K);
+// ws: plan.ws_floats floats of scratch when plan.splitk > 1.  Returns the hipError_t of the launch(es).
+hipError_t launch_gemm(const GemmParams& p, const GemmPlan& plan, float* ws, hipStream_t s);
 
 struct LayerNormParams {
     const float* x; float* y;
@@ -57,7 +61,7 @@ hipError_t launch_layernorm(const LayerNormParams& p, hipStream_t s);
 struct WindowAttnParams {
     const float* qkv;     // [B, H, W, 3C] natural token order (q | k | v, heads-major inside each, swin.rs:218)
     const float* qkv_bias;// [3C]  (q/k/v of a zero pad token)
-    const float* biasT;   // [heads][N key][N query] relative position bias, transposed cached_bias (swin.rs:147-152)
+    const float* rel_table;// relative_position_bias_table [(2*12-1)^2][heads] (swin.rs:138-141); cached_bias (swin.rs:147-152) is never built
     float* out;           // [B, H, W, C]
     int B, H, W, C, heads;
     int Hp, Wp;           // padded canvas (multiples of 12)

@@ -162,7 +162,7 @@ void build_swin_weights(const WeightTable& wt, const std::string& pre, const brn
         out.patch_proj = make_conv_gather(own, w, b, E, IC, P, P, P, 0, 1);
         out.patch_norm = get_ln(wt, pre + "patch_embed.norm", E, own);
     }
-    const int ws = cfg.window_size, N = ws * ws, T = (2 * ws - 1) * (2 * ws - 1);
+    const int ws = cfg.window_size, T = (2 * ws - 1) * (2 * ws - 1);
     for (int i = 0; i < 4; ++i) {
         SwinStageW& st = out.stages[i];
         const int C = E << i, heads = cfg.num_heads[i];
@@ -184,17 +184,7 @@ void build_swin_weights(const WeightTable& wt, const std::string& pre, const brn
             bk.fc1.act = ACT_GELU_ERF;                                  // swin.rs:105
             bk.fc2 = get_linear(wt, bp + "mlp.fc2", C, hidden, true, own);
             const float* table = wt.get(bp + "attn.relative_position_bias_table", {T, heads})->data;
-            // biasT[h][key][query] = table[index[query][key]][h], index = (i-k+ws-1)*(2ws-1) + (j-l+ws-1) (swin.rs:182-184)
-            std::vector<float> bt((size_t)heads * N * N);
-            for (int q = 0; q < N; ++q) {
-                const int qi = q / ws, qj = q % ws;
-                for (int k = 0; k < N; ++k) {
-                    const int ki = k / ws, kj = k % ws;
-                    const int idx = (qi - ki + ws - 1) * (2 * ws - 1) + (qj - kj + ws - 1);
-                    for (int h = 0; h < heads; ++h) bt[((size_t)h * N + k) * N + q] = table[(size_t)idx * heads + h];
-                }
-            }
-            bk.biasT = own.upload(bt);
+            bk.rel_table = own.upload(table, (size_t)T * heads);   // indexed in-kernel: (qi-ki+ws-1)*(2ws-1) + (qj-kj+ws-1), swin.rs:182-184
         }
         st.has_down = i < 3;
         if (st.has_down) {

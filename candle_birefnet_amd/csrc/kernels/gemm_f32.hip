@@ -54,7 +54,10 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_f32_kernel(const GemmParams 
         const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
         swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
-    const int m0 = (swz / tilesN) * BM, n0 = (swz % tilesN) * BN;
+    // split-K: grid = tiles x splitk; slice s of a tile contracts k-tiles [s*kts, (s+1)*kts) and writes raw partial sums
+    const int ntiles = tilesN * ((p.M + BM - 1) / BM);
+    const int slice = swz / ntiles, tile = swz - slice * ntiles;
+    const int m0 = (tile / tilesN) * BM, n0 = (tile % tilesN) * BN;
 
     const int kq = tid & 7, lrow = tid >> 3;
 
@@ -171,14 +174,18 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_f32_kernel(const GemmParams 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = p.K / BK;
+    const int nk_all = p.K / BK;
+    const int kts = (nk_all + p.splitk - 1) / p.splitk;
+    const int kt0 = slice * kts, nk = min(nk_all, kt0 + kts);
     const float* a_frag = As + (wm * WTM + (lane & 31)) * LDS_LD + (lane >> 5) * 16;
     const float* b_frag = Bs + (wn * WTN + (lane & 31)) * LDS_LD + (lane >> 5) * 16;
 
-    gload(0);
-    lds_store();
+    if (kt0 < nk) {
+        gload(kt0);
+        lds_store();
+    }
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt0; kt < nk; ++kt) {
         if (kt + 1 < nk) gload(kt + 1);
 #pragma unroll
         for (int hs = 0; hs < 2; ++hs) {
@@ -214,6 +221,22 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_f32_kernel(const GemmParams 
 
     // ---- epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
     const int col = lane & 31, rhalf = (lane >> 5) * 4;
+    if (p.splitk > 1) {
+        float* part = p.part + (long)slice * p.M * p.N;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WTN + j * 32 + col;
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
+                    if (m < p.M) part[(long)m * p.N + n] = acc[i][j][r];
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * WTN + j * 32 + col;
@@ -239,9 +262,26 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_f32_kernel(const GemmParams 
     }
 }
 
+// split-K second pass: fixed-order sum of the slices (deterministic) + the epilogue of gemm_f32_kernel
+__global__ void splitk_reduce_kernel(const GemmParams p) {
+    const long total = (long)p.M * p.N;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / p.N), n = (int)(idx - (long)m * p.N);
+        float v = 0.f;
+        for (int s = 0; s < p.splitk; ++s) v += p.part[(long)s * total + idx];
+        if (p.bias) v += p.bias[n];
+        if (p.bbias) v += p.bbias[(long)(m / p.bbias_rows) * p.N + n];
+        if (p.scale) v = v * p.scale[n] + p.shift[n];
+        if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+        else if (p.act == ACT_GELU_ERF) v = gelu_erf(v);
+        if (p.R) v += p.R[(long)m * p.ldr + p.r_coff + n];
+        p.C[(long)m * p.ldc + p.c_coff + n] = v;
+    }
+}
+
 template <int BM, int BN, int WM, int WN>
 static hipError_t launch_cfg(const GemmParams& p, hipStream_t s) {
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.splitk;
     dim3 grid(tiles), block(WM * WN * 64);
     switch (p.mode) {
         case GEMM_DENSE: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, GEMM_DENSE>), grid, block, 0, s, p); break;
@@ -253,18 +293,48 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
-    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0) return hipErrorInvalidValue;
-    if ((p.mode == GEMM_CONV_NHWC || p.mode == GEMM_DEFORM_NHWC) && (p.Cin % BK) != 0) return hipErrorInvalidValue;
-    // tile choice: the widest tile that still gives the 256 CUs >= ~2 workgroups each, and no wider in N
-    // than the problem.  W is padded to 128 rows so every config may over-read it safely.
-    const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    const long t12864 = (long)((p.M + 127) / 128) * ((p.N + 63) / 64);
-    const bool n_fits64 = ((p.N + 63) / 64) * 64 < ((p.N + 127) / 128) * 128;  // a 64-wide tile wastes less
-    if (t128 >= 512 && !n_fits64) return launch_cfg<128, 128, 2, 2>(p, s);
-    if (t12864 >= 512) return launch_cfg<128, 64, 2, 2>(p, s);
-    if (t128 >= 384 && !n_fits64) return launch_cfg<128, 128, 2, 2>(p, s);
-    return launch_cfg<64, 64, 2, 2>(p, s);
+// Tile + split-K choice.  The widest tile that still gives the 256 CUs >= ~2 workgroups each and is no wider in N than
+// the problem; when even the 64x64 tiling leaves most CUs idle (tall-K convs on small maps, half-scale Swin GEMMs at
+// batch 1) the K loop is split so that ~512 workgroups exist.  W is padded to 128 rows so every config may over-read it.
+GemmPlan plan_gemm(int M, int N, int K) {
+    GemmPlan pl{2, 1, 0};
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    const long t12864 = (long)((M + 127) / 128) * ((N + 63) / 64);
+    const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
+    const bool n_fits64 = ((N + 63) / 64) * 64 < ((N + 127) / 128) * 128;  // a 64-wide tile wastes less
+    if (t128 >= 512 && !n_fits64) pl.cfg = 0;
+    else if (t12864 >= 512) pl.cfg = 1;
+    else if (t128 >= 384 && !n_fits64) pl.cfg = 0;
+    else {
+        pl.cfg = 2;
+        const int nk = K / BK;
+        if (t64 < 384 && nk >= 8) {
+            int s = (int)((512 + t64 - 1) / t64);
+            if (s > nk / 4) s = nk / 4;
+            if (s > 64) s = 64;
+            if (s > 1) { pl.splitk = s; pl.ws_floats = (size_t)s * M * N; }
+        }
+    }
+    return pl;
+}
+
+hipError_t launch_gemm(const GemmParams& p_in, const GemmPlan& pl, float* ws, hipStream_t s) {
+    if (p_in.M <= 0 || p_in.N <= 0 || p_in.K <= 0 || (p_in.K % BK) != 0) return hipErrorInvalidValue;
+    if ((p_in.mode == GEMM_CONV_NHWC || p_in.mode == GEMM_DEFORM_NHWC) && (p_in.Cin % BK) != 0) return hipErrorInvalidValue;
+    GemmParams p = p_in;
+    p.splitk = pl.splitk < 1 ? 1 : pl.splitk;
+    p.part = ws;
+    if (p.splitk > 1 && !ws) return hipErrorInvalidValue;
+    hipError_t e;
+    if (pl.cfg == 0) e = launch_cfg<128, 128, 2, 2>(p, s);
+    else if (pl.cfg == 1) e = launch_cfg<128, 64, 2, 2>(p, s);
+    else e = launch_cfg<64, 64, 2, 2>(p, s);
+    if (e != hipSuccess || p.splitk == 1) return e;
+    long total = (long)p.M * p.N;
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    return hipGetLastError();
 }
 
 }  // namespace brn

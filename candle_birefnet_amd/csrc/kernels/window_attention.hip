@@ -14,6 +14,7 @@
 //   S^T[key][query] = K . Q^T   A = K fragment (row = key),  B = Q^T (col = query); lane group g = lane>>4
 //                               contracts d = 8g + s at step s (both operands use the same permutation), so a
 //                               lane's 8 q (or k) values are 8 consecutive floats of one row.
+//   bias                        = this head's 529-entry table column in LDS, indexed arithmetically (no [h,144,144] tensor)
 //   softmax over keys           = over the rows of S^T for a fixed column -> in-lane over 36 registers, then
 //                               across the 4 lane groups (shfl_xor 16, 32).
 //   O^T[d][query] = V^T . P^T   B = P^T taken straight from the S^T accumulator registers (lane group g holds keys
@@ -36,6 +37,7 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_f32_kernel(const
     __shared__ __attribute__((aligned(16))) float Vs[NTOK * KV_LD];
     __shared__ int src_s[NTOK];   // source token offset (pixel index) or -1 for a pad token
     __shared__ int rid_s[NTOK];   // SW-MSA region id of the token (swin.rs:608-629)
+    __shared__ float tab_s[(2 * WS - 1) * (2 * WS - 1)];   // this head's column of relative_position_bias_table
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int head = blockIdx.y;
@@ -56,6 +58,7 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_f32_kernel(const
         const int fw = pw < p.Wp - WS ? 0 : (pw < p.Wp - p.shift ? 1 : 2);
         rid_s[tid] = fh * 3 + fw;
     }
+    for (int i = tid; i < (2 * WS - 1) * (2 * WS - 1); i += ATT_THREADS) tab_s[i] = p.rel_table[i * p.heads + head];
     __syncthreads();
 
     // ---- stage K and V of this (window, head) into LDS: 144 rows x 8 float4 each ----
@@ -71,12 +74,13 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_f32_kernel(const
     __syncthreads();
 
     const int li = lane & 15, g = lane >> 4;
-    const float* biasT = p.biasT + (long)head * NTOK * NTOK;
 
     for (int qt = wave; qt < 9; qt += 3) {
         const int qtok = qt * 16 + li;
         const int qsrc = src_s[qtok];
         const int qrid = rid_s[qtok];
+        // relative position index (swin.rs:182-184): (qi-ki+11)*23 + (qj-kj+11) = qbase - (key + 11*(key/12))
+        const int qbase = (qtok / WS + WS - 1) * (2 * WS - 1) + (qtok % WS) + WS - 1;
         // Q fragment: d = 8g .. 8g+7 of query row qtok, scaled before the product (swin.rs:278)
         float qf[8];
         {
@@ -99,6 +103,7 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_f32_kernel(const
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k1[e], qf[4 + e], acc, 0, 0, 0);
             st[kt] = acc;
+            if (kt % 3 == 2) __builtin_amdgcn_sched_barrier(0);   // bound the scheduler's hoisting (register pressure)
         }
         // + relative position bias (swin.rs:284-285), + SW-MSA mask (swin.rs:288-297, value -100 swin.rs:651)
         float mx = -3.0e38f;
@@ -107,7 +112,7 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_f32_kernel(const
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = kt * 16 + g * 4 + r;
-                float s = st[kt][r] + biasT[key * NTOK + qtok];
+                float s = st[kt][r] + tab_s[qbase - key - 11 * (key / WS)];
                 if (p.shift > 0) s += (rid_s[key] != qrid) ? -100.0f : 0.0f;
                 st[kt][r] = s;
                 mx = fmaxf(mx, s);
@@ -120,7 +125,7 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_f32_kernel(const
         for (int kt = 0; kt < 9; ++kt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = expf(st[kt][r] - mx);
+                const float e = __expf(st[kt][r] - mx);
                 st[kt][r] = e;
                 sum += e;
             }
@@ -137,6 +142,7 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_f32_kernel(const
                 o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[0], st[kt][r], o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[16], st[kt][r], o1, 0, 0, 0);
             }
+            if (kt % 2 == 1) __builtin_amdgcn_sched_barrier(0);
         }
         // lane holds O^T[d = 16*dt + 4g + r][query = li]; softmax denominator applied here (swin.rs:300,303)
         if (qsrc >= 0) {

@@ -190,6 +190,12 @@ brn_status brn_deform_conv2d_forward(const float* x, int B, int C, int H, int W,
                                      const float* w, const float* bias, int O, int k, int stride, int pad,
                                      int mode, float* y, brn_mem loc, int device_ordinal, void* stream);
 
+/* ---- diagnostics ---------------------------------------------------------------------------------------- */
+/* Times `iters` launches of the dense gemm_f32 kernel on random device data (M x K times N x K^T).  tile_cfg: -1 = the
+ * library's own plan, 0 = 128x128, 1 = 128x64, 2 = 64x64 block tile; splitk only with tile_cfg >= 0.  Tuning aid. */
+brn_status brn_gemm_microbench(int M, int N, int K, int tile_cfg, int splitk, int iters, int device_ordinal,
+                               float* ms_per_launch);
+
 #ifdef __cplusplus
 }
 #endif
