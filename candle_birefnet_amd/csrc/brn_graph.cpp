@@ -155,46 +155,69 @@ void swin_stage_dims(int H, int W, int patch, int hs[4], int ws[4]) {
     }
 }
 
-void swin_attention(Ctx& c, const SwinBlockW& blk, const float* xn, int B, int H, int W, int C, int shift, float* y,
-                    const float* residual) {
+// The attention half of a block for `nin` token sets that share the weights (the full- and half-scale backbone passes
+// of birefnet.rs:416,426 are run as ONE pass over concatenated token rows: every per-token op sees M = M_full + M_half).
+static void swin_attention_multi(Ctx& c, const SwinBlockW& blk, const float* xn, int B, int nin, const int* hs, const int* wsz, int C,
+                                 int shift, float* y, const float* residual) {
     const size_t mk = c.arena->mark();
-    const int M = B * H * W;
+    int M = 0;
+    for (int k = 0; k < nin; ++k) M += B * hs[k] * wsz[k];
     float* qkv = c.arena->alloc((size_t)M * 3 * C);
     float* att = c.arena->alloc((size_t)M * C);
     run_gemm(c, blk.qkv, xn, M, C, qkv, 3 * C, 0);                   // swin.rs:217 (pad rows are synthesised by the kernel)
-    if (!c.dry) {
-        WindowAttnParams p{};
-        p.qkv = qkv; p.qkv_bias = blk.qkv.bias; p.rel_table = blk.rel_table; p.out = att;
-        p.B = B; p.H = H; p.W = W; p.C = C; p.heads = blk.heads;
-        p.Hp = roundup(H, 12); p.Wp = roundup(W, 12);                // swin.rs:359-360
-        p.shift = shift; p.scale = 1.0f / sqrtf(32.0f);              // head_dim^-0.5 (swin.rs:134)
-        const double nwin = (double)B * (p.Hp / 12) * (p.Wp / 12) * blk.heads;
-        Bracket b(c, FAM_ATTENTION, nwin * 2.0 * 2.0 * 144 * 144 * 32, 4.0 * ((double)M * 4 * C), M, C, shift);
-        BRN_LAUNCH(launch_window_attention(p, c.stream));
+    size_t off = 0;
+    for (int k = 0; k < nin; ++k) {
+        const int Mk = B * hs[k] * wsz[k];
+        if (!c.dry) {
+            WindowAttnParams p{};
+            p.qkv = qkv + off * 3 * C; p.qkv_bias = blk.qkv.bias; p.rel_table = blk.rel_table; p.out = att + off * C;
+            p.B = B; p.H = hs[k]; p.W = wsz[k]; p.C = C; p.heads = blk.heads;
+            p.Hp = roundup(hs[k], 12); p.Wp = roundup(wsz[k], 12);   // swin.rs:359-360
+            p.shift = shift; p.scale = 1.0f / sqrtf(32.0f);          // head_dim^-0.5 (swin.rs:134)
+            const double nwin = (double)B * (p.Hp / 12) * (p.Wp / 12) * blk.heads;
+            Bracket b(c, FAM_ATTENTION, nwin * 2.0 * 2.0 * 144 * 144 * 32, 4.0 * ((double)Mk * 4 * C), Mk, C, shift);
+            BRN_LAUNCH(launch_window_attention(p, c.stream));
+        }
+        off += Mk;
     }
     run_gemm(c, blk.proj, att, M, C, y, C, 0, residual, C, 0);      // swin.rs:310 (+ shortcut, swin.rs:406)
     c.arena->release(mk);
 }
 
-void swin_forward(Ctx& c, const SwinW& w, const float* img, int B, int H, int W, const Map outs[4]) {
-    int hs[4], wsz[4];
-    swin_stage_dims(H, W, w.patch, hs, wsz);
+void swin_attention(Ctx& c, const SwinBlockW& blk, const float* xn, int B, int H, int W, int C, int shift, float* y,
+                    const float* residual) {
+    swin_attention_multi(c, blk, xn, B, 1, &H, &W, C, shift, y, residual);
+}
+
+void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int B) {
+    if (nin < 1 || nin > 2) fail(BRN_ERR_INVALID_ARG, "swin_forward_multi: 1 or 2 inputs");
+    int hs[2][4], wsz[2][4];
+    for (int k = 0; k < nin; ++k) swin_stage_dims(ins[k].H, ins[k].W, w.patch, hs[k], wsz[k]);
+    auto rows = [&](int k, int i) { return B * hs[k][i] * wsz[k][i]; };
+    auto total = [&](int i) { int m = 0; for (int k = 0; k < nin; ++k) m += rows(k, i); return m; };
     const size_t mk0 = c.arena->mark();
     const int E = w.embed_dim;
     // PatchEmbed (swin.rs:692-714): conv k4 s4 straight from the NCHW image (zero beyond the border = pad_with_zeros), LN
-    float* x = c.arena->alloc((size_t)B * hs[0] * wsz[0] * E);
+    float* x = c.arena->alloc((size_t)total(0) * E);
     {
         const size_t mk = c.arena->mark();
-        Map t = new_map(c, B, hs[0], wsz[0], E);
-        run_conv_nchw(c, w.patch_proj, img, B, H, W, t);
-        run_layernorm(c, w.patch_norm, t.p, B * hs[0] * wsz[0], E, x, E, 0);
+        float* t = c.arena->alloc((size_t)total(0) * E);
+        size_t off = 0;
+        for (int k = 0; k < nin; ++k) {
+            Map tm; tm.p = t + off * E; tm.B = B; tm.H = hs[k][0]; tm.W = wsz[k][0]; tm.C = E; tm.ld = E; tm.coff = 0;
+            run_conv_nchw(c, w.patch_proj, ins[k].img, B, ins[k].H, ins[k].W, tm);
+            off += rows(k, 0);
+        }
+        run_layernorm(c, w.patch_norm, t, total(0), E, x, E, 0);
         c.arena->release(mk);
     }
     for (int i = 0; i < 4; ++i) {
         const SwinStageW& st = w.stages[i];
-        const int C = st.C, h = hs[i], ww = wsz[i], M = B * h * ww;
+        const int C = st.C, M = total(i);
+        int hh[2], ww[2];
+        for (int k = 0; k < nin; ++k) { hh[k] = hs[k][i]; ww[k] = wsz[k][i]; }
         float* xnext = nullptr;
-        if (st.has_down) xnext = c.arena->alloc((size_t)B * hs[i + 1] * wsz[i + 1] * 2 * C);
+        if (st.has_down) xnext = c.arena->alloc((size_t)total(i + 1) * 2 * C);
         const size_t mk = c.arena->mark();
         float* xn = c.arena->alloc((size_t)M * C);
         const int hidden = st.blocks.empty() ? 4 * C : st.blocks[0].fc1.N;
@@ -203,33 +226,43 @@ void swin_forward(Ctx& c, const SwinW& w, const float* img, int B, int H, int W,
             const SwinBlockW& bk = st.blocks[j];
             const int shift = (j % 2 == 0) ? 0 : w.window / 2;                       // swin.rs:552
             run_layernorm(c, bk.norm1, x, M, C, xn, C, 0);                            // swin.rs:355
-            swin_attention(c, bk, xn, B, h, ww, C, shift, x, x);                      // x = shortcut + attn (swin.rs:406)
+            swin_attention_multi(c, bk, xn, B, nin, hh, ww, C, shift, x, x);          // x = shortcut + attn (swin.rs:406)
             run_layernorm(c, bk.norm2, x, M, C, xn, C, 0);                            // swin.rs:407
             run_gemm(c, bk.fc1, xn, M, C, hid, hidden, 0);                            // fc1 + gelu_erf (swin.rs:104-105)
             run_gemm(c, bk.fc2, hid, M, hidden, x, C, 0, x, C, 0);                    // x + fc2(...) (swin.rs:106,407)
         }
         // stage output = norm_i(x_out), pre-downsample (swin.rs:591,784-789); written into its consumer's window
-        if (outs[i].B != B || outs[i].H != h || outs[i].W != ww || outs[i].C != C)
-            fail(BRN_ERR_INVALID_ARG, "swin output window %d has the wrong shape", i);
-        run_layernorm(c, st.out_norm, x, M, C, outs[i].p, outs[i].ld, outs[i].coff);
-        if (st.has_down) {
-            // PatchMerging (swin.rs:491-527): gather 2x2 + LN(4C) fused, then the bias-free reduction
-            const int M2 = B * hs[i + 1] * wsz[i + 1];
-            float* pm = c.arena->alloc((size_t)M2 * 4 * C);
-            if (!c.dry) {
-                LayerNormParams p{};
-                p.x = x; p.y = pm; p.rows = M2; p.C = 4 * C; p.gamma = st.down_norm.g; p.beta = st.down_norm.b; p.eps = 1e-5f;
-                p.ldy = 4 * C; p.y_coff = 0; p.mode = 1; p.H = h; p.W = ww; p.Cin = C;
-                Bracket b(c, FAM_LAYERNORM, 0.0, 8.0 * M2 * 4.0 * C);
-                BRN_LAUNCH(launch_layernorm(p, c.stream));
+        size_t off = 0, off2 = 0;
+        float* pm = nullptr;
+        if (st.has_down) pm = c.arena->alloc((size_t)total(i + 1) * 4 * C);
+        for (int k = 0; k < nin; ++k) {
+            const Map& o = ins[k].outs[i];
+            if (o.B != B || o.H != hh[k] || o.W != ww[k] || o.C != C) fail(BRN_ERR_INVALID_ARG, "swin output window %d has the wrong shape", i);
+            run_layernorm(c, st.out_norm, x + off * C, rows(k, i), C, o.p, o.ld, o.coff);
+            if (st.has_down) {
+                // PatchMerging (swin.rs:491-527): gather 2x2 + LN(4C) fused, then the bias-free reduction (below, once)
+                const int M2 = rows(k, i + 1);
+                if (!c.dry) {
+                    LayerNormParams p{};
+                    p.x = x + off * C; p.y = pm + off2 * 4 * C; p.rows = M2; p.C = 4 * C; p.gamma = st.down_norm.g; p.beta = st.down_norm.b;
+                    p.eps = 1e-5f; p.ldy = 4 * C; p.y_coff = 0; p.mode = 1; p.H = hh[k]; p.W = ww[k]; p.Cin = C;
+                    Bracket b(c, FAM_LAYERNORM, 0.0, 8.0 * M2 * 4.0 * C);
+                    BRN_LAUNCH(launch_layernorm(p, c.stream));
+                }
+                off2 += M2;
             }
-            run_gemm(c, st.reduction, pm, M2, 4 * C, xnext, 2 * C, 0);
+            off += rows(k, i);
         }
+        if (st.has_down) run_gemm(c, st.reduction, pm, total(i + 1), 4 * C, xnext, 2 * C, 0);
         c.arena->release(mk);
-        // x of this stage is dead now; xnext lives just above it on the stack.  (Stack discipline keeps both until mk0.)
         x = xnext;
     }
     c.arena->release(mk0);
+}
+
+void swin_forward(Ctx& c, const SwinW& w, const float* img, int B, int H, int W, const Map outs[4]) {
+    SwinIn in{img, H, W, outs};
+    swin_forward_multi(c, w, &in, 1, B);
 }
 
 // ---- BasicDecBlk (decoder.rs:126-141) with ASPPDeformable (aspp.rs:303-333) ------------------------------------------------
@@ -365,11 +398,7 @@ void model_forward(Model& m, Ctx& c, const float* img, int B, int H, int W, floa
     Map X4 = new_map(c, B, h4, w4, 5760);
     stamp(0);
     {
-        Map outs[4] = {X1.window(0, 192), X2.window(0, 384), X3.window(0, 768), X4.window(2688, 1536)};
-        swin_forward(c, m.swin, img, B, H, W, outs);                                  // birefnet.rs:416
-    }
-    stamp(1);
-    {
+        // both backbone passes (birefnet.rs:416 and :426) as one pass over concatenated token rows
         const size_t mk2 = c.arena->mark();
         const int Hh = H / 2, Wh = W / 2;
         float* half = c.arena->alloc((size_t)B * 3 * Hh * Wh);
@@ -381,7 +410,10 @@ void model_forward(Model& m, Ctx& c, const float* img, int B, int H, int W, floa
         swin_stage_dims(Hh, Wh, m.swin.patch, hs, ws);
         Map hm[4];
         for (int i = 0; i < 4; ++i) hm[i] = new_map(c, B, hs[i], ws[i], 192 << i);
-        swin_forward(c, m.swin, half, B, Hh, Wh, hm);                                 // birefnet.rs:426
+        Map outs[4] = {X1.window(0, 192), X2.window(0, 384), X3.window(0, 768), X4.window(2688, 1536)};
+        SwinIn ins[2] = {{img, H, W, outs}, {half, Hh, Wh, hm}};
+        swin_forward_multi(c, m.swin, ins, 2, B);
+        stamp(1);
         run_resize(c, hm[0], X1.window(192, 192));                                    // birefnet.rs:435-443
         run_resize(c, hm[1], X2.window(384, 384));
         run_resize(c, hm[2], X3.window(768, 768));

@@ -179,6 +179,9 @@ void run_resize(Ctx& c, const Map& in, const Map& out);
 // SwinTransformer::forward (swin.rs:768-797): outs[i] are destination windows (stage outputs after norm_i)
 void swin_forward(Ctx& c, const SwinW& w, const float* img_nchw, int B, int H, int W, const Map outs[4]);
 void swin_stage_dims(int H, int W, int patch, int hs[4], int ws[4]);
+struct SwinIn { const float* img; int H, W; const Map* outs; };   // one backbone input and its 4 destination windows
+// 1 or 2 inputs through the same weights in one pass over concatenated token rows
+void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int B);
 // the attention half of one block (swin.rs:356-403), x is the norm1 output, y = proj(attn) (no residual) or += residual
 void swin_attention(Ctx& c, const SwinBlockW& blk, const float* xn, int B, int H, int W, int C, int shift,
                     float* y, const float* residual);

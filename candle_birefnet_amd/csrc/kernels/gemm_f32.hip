@@ -237,6 +237,8 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_f32_kernel(const GemmParams 
         }
         return;
     }
+    // Loads of a 32x32 tile's residual / per-image-bias values are issued together (16 independent loads in flight),
+    // the uniform epilogue switches are taken once per tile, not per element.
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * WTN + j * 32 + col;
@@ -246,20 +248,65 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_f32_kernel(const GemmParams 
         const float sh = p.shift ? p.shift[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            const int mbase = m0 + wm * WTM + i * 32 + rhalf;
+            float rv[16], bb[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { rv[r] = 0.f; bb[r] = 0.f; }
+            if (p.R) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    if (m < p.M) rv[r] = p.R[(long)m * p.ldr + p.r_coff + n];
+                }
+            }
+            if (p.bbias) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    if (m < p.M) bb[r] = p.bbias[(long)(m / p.bbias_rows) * p.N + n];
+                }
+            }
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = ((acc[i][j][r] + bias) + bb[r]) * sc + sh;
+            if (p.act == ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+            } else if (p.act == ACT_GELU_ERF) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = gelu_erf(v[r]);
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
-                if (m >= p.M) continue;
-                float v = acc[i][j][r] + bias;
-                if (p.bbias) v += p.bbias[(long)(m / p.bbias_rows) * p.N + n];
-                if (p.scale) v = v * sc + sh;
-                if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-                else if (p.act == ACT_GELU_ERF) v = gelu_erf(v);
-                if (p.R) v += p.R[(long)m * p.ldr + p.r_coff + n];
-                p.C[(long)m * p.ldc + p.c_coff + n] = v;
+                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                if (m < p.M) p.C[(long)m * p.ldc + p.c_coff + n] = v[r] + rv[r];
             }
         }
     }
+}
+
+// diagnostic: back-to-back v_mfma_f32_32x32x2_f32 on register operands (4 independent accumulators per wave); lane 0 of
+// each wave reports shader-clock / 100 MHz-realtime-clock ticks so the host can derive the sustained clock
+__global__ void mfma_peak_kernel(int iters, float* sink, unsigned long long* clk) {
+    f32x16 a0, a1, a2, a3;
+    for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; a2[r] = 0.f; a3[r] = 0.f; }
+    float x = (float)(threadIdx.x & 7) * 0.125f - 0.4f, y = (float)(threadIdx.x & 3) * 0.25f - 0.3f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, y, a3, 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float acc = 0.f;
+    for (int r = 0; r < 16; ++r) acc += a0[r] + a1[r] + a2[r] + a3[r];
+    if (acc == 123.456f) sink[0] = acc;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
+}
+hipError_t launch_mfma_peak(int blocks, int iters, float* sink, unsigned long long* clk, hipStream_t s) {
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, s, iters, sink, clk);
+    return hipGetLastError();
 }
 
 // split-K second pass: fixed-order sum of the slices (deterministic) + the epilogue of gemm_f32_kernel
@@ -293,27 +340,29 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
-// Tile + split-K choice.  The widest tile that still gives the 256 CUs >= ~2 workgroups each and is no wider in N than
-// the problem; when even the 64x64 tiling leaves most CUs idle (tall-K convs on small maps, half-scale Swin GEMMs at
-// batch 1) the K loop is split so that ~512 workgroups exist.  W is padded to 128 rows so every config may over-read it.
+// Tile + split-K choice from a small cost model calibrated on MI355X sweeps (tools/gemm_bench.py): a CU's matrix pipe is
+// shared by its resident workgroups, so a launch lasts ~ ceil(tiles / 256 CUs) x (tile area / efficiency of the config).
+// When even the 64x64 tiling leaves most CUs idle (tall-K convs on small maps, half-scale Swin GEMMs at batch 1) the K
+// loop is split so that ~512 workgroups exist.  W is padded to 128 rows so every config may over-read it.
 GemmPlan plan_gemm(int M, int N, int K) {
+    struct Cand { int cfg, bm, bn; double eff; };
+    static const Cand cands[] = {{0, 128, 128, 1.00}, {1, 128, 64, 0.98}, {2, 64, 64, 0.93}, {5, 128, 128, 1.04}, {4, 256, 128, 1.06}};
     GemmPlan pl{2, 1, 0};
-    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-    const long t12864 = (long)((M + 127) / 128) * ((N + 63) / 64);
+    double best = 1e300;
+    for (const Cand& c : cands) {
+        const long tiles = (long)((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn);
+        if ((c.cfg == 5 || c.cfg == 4) && tiles < 1024) continue;      // the 8-wave tiles only pay on large grids
+        const double cost = (double)((tiles + 255) / 256) * c.bm * c.bn / c.eff;
+        if (cost < best) { best = cost; pl.cfg = c.cfg; }
+    }
     const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
-    const bool n_fits64 = ((N + 63) / 64) * 64 < ((N + 127) / 128) * 128;  // a 64-wide tile wastes less
-    if (t128 >= 512 && !n_fits64) pl.cfg = 0;
-    else if (t12864 >= 512) pl.cfg = 1;
-    else if (t128 >= 384 && !n_fits64) pl.cfg = 0;
-    else {
+    const int nk = K / BK;
+    if (t64 < 384 && nk >= 8) {
         pl.cfg = 2;
-        const int nk = K / BK;
-        if (t64 < 384 && nk >= 8) {
-            int s = (int)((512 + t64 - 1) / t64);
-            if (s > nk / 4) s = nk / 4;
-            if (s > 64) s = 64;
-            if (s > 1) { pl.splitk = s; pl.ws_floats = (size_t)s * M * N; }
-        }
+        int s = (int)((768 + t64 - 1) / t64);
+        if (s > nk / 4) s = nk / 4;
+        if (s > 64) s = 64;
+        if (s > 1) { pl.splitk = s; pl.ws_floats = (size_t)s * M * N; }
     }
     return pl;
 }
@@ -328,6 +377,9 @@ hipError_t launch_gemm(const GemmParams& p_in, const GemmPlan& pl, float* ws, hi
     hipError_t e;
     if (pl.cfg == 0) e = launch_cfg<128, 128, 2, 2>(p, s);
     else if (pl.cfg == 1) e = launch_cfg<128, 64, 2, 2>(p, s);
+    else if (pl.cfg == 3) e = launch_cfg<128, 128, 2, 4>(p, s);
+    else if (pl.cfg == 4) e = launch_cfg<256, 128, 4, 2>(p, s);
+    else if (pl.cfg == 5) e = launch_cfg<128, 128, 4, 2>(p, s);
     else e = launch_cfg<64, 64, 2, 2>(p, s);
     if (e != hipSuccess || p.splitk == 1) return e;
     long total = (long)p.M * p.N;

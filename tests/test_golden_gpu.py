@@ -39,10 +39,13 @@ def test_hip_model_goldens_and_oracle(gpu, tag):
     e_orc = _gate(y, O.forward_logits(O.cfg_from(cfg), w, x))
     print(f"{tag}: max abs err vs golden(fp64) {e_gold:.2e}, vs oracle(fp32) {e_orc:.2e}")
     assert e_gold < 1e-4 and e_orc < 1e-4
-    # batch independence = the sharding invariant: each image alone gives the same bits as inside the batch
+    # batch independence = the sharding invariant: an image alone equals the same image inside a batch up to fp32
+    # reorder noise (the tile / split-K plan of a GEMM depends on M, so the summation order may differ with the batch
+    # size); the SAME call repeated is bit-identical (no float atomics anywhere).
     if x.shape[0] > 1:
         for b in range(x.shape[0]):
-            np.testing.assert_array_equal(m.forward_logits(x[b:b + 1])[0], y[b])
+            np.testing.assert_allclose(m.forward_logits(x[b:b + 1])[0], y[b], rtol=0, atol=5e-6)
+        np.testing.assert_array_equal(m.forward_logits(x), y)
     m.close()
 
 

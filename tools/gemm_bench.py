@@ -17,8 +17,8 @@ def run(M, N, K, cfg=-1, sk=1, iters=20):
 
 
 if __name__ == "__main__":
-    print(f"{'M':>6} {'N':>5} {'K':>6} | plan     | 128x128  | 128x64   | 64x64    | 64x64 sk2 | sk4      | sk8   (TF/s)")
+    print(f"{'M':>6} {'N':>5} {'K':>6} | plan     | 128x128  | 128x64   | 64x64    | 128² 8w24 | 256x128  | 128² 8w42 (TF/s)")
     for M, N, K in SHAPES:
         fl = 2.0 * M * N * K / 1e9
-        cells = [run(M, N, K)] + [run(M, N, K, c, 1) for c in (0, 1, 2)] + [run(M, N, K, 2, s) for s in (2, 4, 8)]
+        cells = [run(M, N, K)] + [run(M, N, K, c, 1) for c in (0, 1, 2, 3, 4, 5)]
         print(f"{M:6d} {N:5d} {K:6d} | " + " | ".join(f"{fl / ms:8.1f}" for ms in cells), flush=True)
