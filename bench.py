@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--deform-mode", default="reference_cpu", choices=["reference_cpu", "deformable"])
+    ap.add_argument("--compute", default="f32", choices=["f32", "f32_split3", "f32_split2", "bf16_operands"],
+                    help="arithmetic of the contraction kernels (include/birefnet_hip.h brn_dtype)")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra steps with per-launch HIP events for the roofline block")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off", "on"])
     ap.add_argument("--cpu-baseline-size", type=int, default=0, help="image side for the CPU oracle sample (0 = choose)")
@@ -66,7 +68,7 @@ def main():
     S, B = args.size, args.batch
     cfg = cb.BiRefNetConfig(deform_mode=args.deform_mode)                   # BiRefNetConfig::swin_l()
     weights = cb.synth_weights(cb.birefnet_weight_spec(cfg), seed=42)       # random-init weights of the real architecture
-    model = cb.BiRefNet.new(cfg, cb.VarBuilder.from_tensors(weights), device=local_rank, max_batch=B, max_size=(S, S))
+    model = cb.BiRefNet.new(cfg, cb.VarBuilder.from_tensors(weights), device=local_rank, max_batch=B, max_size=(S, S), compute=args.compute)
     # rank r owns images [r*B, (r+1)*B) of the global batch (seed 1000 + global index)
     x = torch.from_numpy(cb.synth_input(B, S, S, seed0=1000 + rank * B)).cuda()
 

@@ -41,13 +41,16 @@ class _Piece:
 class BiRefNet:
     """birefnet.rs:380-385.  `BiRefNet.new(config, vb)` == BiRefNet::new (birefnet.rs:389)."""
 
-    def __init__(self, config: BiRefNetConfig, vb: VarBuilder, device: int = 0, max_batch: int = 0, max_size=(0, 0)):
+    COMPUTE = {"f32": _ffi.BRN_F32, "f32_split3": _ffi.BRN_F32_SPLIT3, "f32_split2": _ffi.BRN_F32_SPLIT2, "bf16_operands": _ffi.BRN_BF16_OPERANDS}
+
+    def __init__(self, config: BiRefNetConfig, vb: VarBuilder, device: int = 0, max_batch: int = 0, max_size=(0, 0), compute: str = "f32"):
         self.config = config
+        self.compute = compute
         self._h = C.c_void_p()
         self._device = device
         arr, keep = _named_array(vb.tensors_under_prefix())
         cfg = config.to_c()
-        _ffi.check(_ffi.lib.brn_model_create(C.byref(cfg), arr, len(arr), device, _ffi.BRN_F32, int(max_batch),
+        _ffi.check(_ffi.lib.brn_model_create(C.byref(cfg), arr, len(arr), device, self.COMPUTE[compute], int(max_batch),
                                              int(max_size[0]), int(max_size[1]), C.byref(self._h)))
         del keep
         self.backbone = _Piece(self, "backbone")

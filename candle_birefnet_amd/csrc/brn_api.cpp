@@ -229,7 +229,13 @@ brn_status brn_model_create(const brn_config* cfg, const brn_named_tensor* weigh
                             int max_batch, int max_h, int max_w, brn_model** out) {
     return guarded([&] {
         if (!cfg || !weights || !out) fail(BRN_ERR_INVALID_ARG, "null argument");
-        if (dt != BRN_F32) fail(BRN_ERR_INVALID_ARG, "unsupported compute dtype %d (this build computes in fp32)", (int)dt);
+        int planes = 0;
+        if (dt == BRN_F32) planes = 0;
+        else if (dt == BRN_F32_SPLIT3) planes = 3;
+        else if (dt == BRN_F32_SPLIT2) planes = 2;
+        else if (dt == BRN_BF16_OPERANDS) planes = 1;
+        else fail(BRN_ERR_INVALID_ARG, "unsupported compute dtype %d", (int)dt);
+        struct PlanesGuard { PlanesGuard(int p) { set_build_planes(p); } ~PlanesGuard() { set_build_planes(0); } } guard(planes);
         *out = nullptr;
         ensure_device(device);
         validate_config(*cfg);
@@ -625,8 +631,13 @@ brn_status brn_gemm_microbench(int M, int N, int K, int tile_cfg, int splitk, in
         auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xFFFF) / 32768.0f - 1.0f; };
         for (auto& v : ha) v = rnd();
         for (size_t i = 0; i < (size_t)N * K; ++i) hw[i] = rnd();
+        int planes = 0;
+        if (tile_cfg >= 1000) { planes = tile_cfg / 1000; tile_cfg %= 1000; if (tile_cfg == 999) tile_cfg = -1; }
         float* dA = own.upload(ha);
-        float* dW = own.upload(hw);
+        set_build_planes(planes);
+        GemmW gw = make_linear(own, hw.data(), nullptr, N, K);
+        set_build_planes(0);
+        float* dW = gw.w;
         std::vector<float> hc((size_t)M * N, 0.f);
         float* dC = own.upload(hc);
         GemmPlan pl = plan_gemm(M, N, K);
@@ -635,6 +646,7 @@ brn_status brn_gemm_microbench(int M, int N, int K, int tile_cfg, int splitk, in
         if (pl.ws_floats) { std::vector<float> z(pl.ws_floats, 0.f); ws = own.upload(z); }
         GemmParams p{};
         p.A = dA; p.W = dW; p.C = dC; p.M = M; p.N = N; p.K = K; p.mode = GEMM_DENSE; p.lda = K; p.ldc = N; p.bbias_rows = 1;
+        p.Wp = gw.wp; p.planes = gw.planes; p.wp_rows = gw.wp_rows;
         hipEvent_t e0, e1;
         BRN_HIP(hipEventCreate(&e0)); BRN_HIP(hipEventCreate(&e1));
         for (int i = 0; i < 3; ++i) BRN_HIP(launch_gemm(p, pl, ws, nullptr));

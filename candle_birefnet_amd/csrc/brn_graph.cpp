@@ -54,6 +54,7 @@ struct Bracket {
 // ---- GEMM-shaped pieces -------------------------------------------------------------------------------------------------
 static void fill_epilogue(GemmParams& p, const GemmW& w) {
     p.bias = w.bias; p.scale = w.scale; p.shift = w.shift; p.act = w.act;
+    p.Wp = w.wp; p.planes = w.planes; p.wp_rows = w.wp_rows;
 }
 
 void run_gemm(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* C, int ldc, int c_coff, const float* R, int ldr,

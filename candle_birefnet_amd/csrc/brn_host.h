@@ -68,6 +68,8 @@ struct DevVec { float* p = nullptr; size_t n = 0; };
 
 struct GemmW {          // one Linear / Conv2d, repacked for gemm_f32
     float* w = nullptr; // [roundup(N,128)][K]
+    void* wp = nullptr; // split-bf16 path: [planes][roundup(N,128)][K] bf16 planes of the same matrix (or null)
+    int planes = 0, wp_rows = 0;
     int N = 0, K = 0, Kreal = 0;
     int Cin = 0, Cinp = 0, kh = 1, kw = 1, stride = 1, pad = 0, dil = 1;
     int mode = GEMM_DENSE;
@@ -191,5 +193,8 @@ void decoder_forward(Ctx& c, const Model& m, const float* img_nchw, int B, int H
 void model_forward(Model& m, Ctx& c, const float* img_nchw, int B, int H, int W, float* out, int apply_sigmoid);
 
 void ensure_device(int ordinal);
+// number of bf16 planes the weight builders attach to every dense / channels-last conv GemmW (0 = fp32 MFMA path only)
+void set_build_planes(int planes);
+int build_planes();
 
 }  // namespace brn

@@ -37,6 +37,8 @@ struct GemmParams {
     int act;
     const float* R; int ldr; int r_coff;
     int ldc; int c_coff;
+    // split-bf16 path (planes = 0: fp32 MFMA path): Wp = W pre-split into `planes` bf16 planes [planes][wp_rows][K]
+    const void* Wp; int planes; int wp_rows;
     // split-K (filled by launch_gemm from the plan): slices write raw partials to part[slice][M][N]
     int splitk; float* part;
 };

@@ -69,6 +69,44 @@ const brn_named_tensor* WeightTable::get(const std::string& name, std::initializ
 
 static inline int roundup(int x, int m) { return (x + m - 1) / m * m; }
 
+static thread_local int g_build_planes = 0;
+void set_build_planes(int planes) { g_build_planes = planes; }
+int build_planes() { return g_build_planes; }
+
+static inline uint16_t bf16_rne(float x) {            // round-to-nearest-even fp32 -> bf16 (finite inputs)
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_f32(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+// error-free split of the packed fp32 matrix into bf16 planes: plane p = RN_bf16(x - sum of the previous planes)
+static void attach_planes(DeviceOwner& own, GemmW& g, const std::vector<float>& pk, int rows) {
+    const int np = g_build_planes;
+    if (np <= 0) return;
+    const size_t n = pk.size();
+    std::vector<uint16_t> planes(n * np);
+    for (size_t i = 0; i < n; ++i) {
+        float r = pk[i];
+        for (int p = 0; p < np; ++p) {
+            const uint16_t h = bf16_rne(r);
+            planes[(size_t)p * n + i] = h;
+            r -= bf16_to_f32(h);
+        }
+    }
+    void* d = nullptr;
+    hipError_t e = hipMalloc(&d, planes.size() * 2 + 16);
+    if (e != hipSuccess) fail(BRN_ERR_OOM, "hipMalloc of %zu bytes failed: %s", planes.size() * 2, hipGetErrorString(e));
+    own.ptrs.push_back(d);
+    BRN_HIP(hipMemcpy(d, planes.data(), planes.size() * 2, hipMemcpyHostToDevice));
+    g.wp = d; g.planes = np; g.wp_rows = rows;
+}
+
 // ---- repack helpers ------------------------------------------------------------------------------------------------
 GemmW make_linear(DeviceOwner& own, const float* w, const float* bias, int N, int K) {
     if (K % 32) fail(BRN_ERR_INVALID_ARG, "linear in_features %d must be a multiple of 32", K);
@@ -77,6 +115,7 @@ GemmW make_linear(DeviceOwner& own, const float* w, const float* bias, int N, in
     std::vector<float> pk((size_t)roundup(N, 128) * K, 0.f);
     memcpy(pk.data(), w, (size_t)N * K * sizeof(float));
     g.w = own.upload(pk);
+    attach_planes(own, g, pk, roundup(N, 128));
     if (bias) g.bias = own.upload(bias, N);
     return g;
 }
@@ -95,6 +134,7 @@ GemmW make_conv_nhwc(DeviceOwner& own, const float* w, const float* bias, int O,
                 for (int kx = 0; kx < kw; ++kx)
                     pk[(size_t)o * g.K + (size_t)(ky * kw + kx) * cinp + ci] = w[(((size_t)o * Cin + ci) * kh + ky) * kw + kx];
     g.w = own.upload(pk);
+    attach_planes(own, g, pk, roundup(O, 128));
     if (bias) g.bias = own.upload(bias, O);
     return g;
 }

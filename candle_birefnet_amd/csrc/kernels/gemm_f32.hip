@@ -30,6 +30,98 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
+// ---- epilogue shared by the fp32-MFMA and the split-bf16 kernels (same 32x32 C/D register map) ----
+// Each 32x32 accumulator tile is transposed through a wave-private LDS patch (rows of 36 floats) so that the global side
+// is row-major float4: 8 lanes cover one 128-byte row segment, residual / per-image-bias loads and the stores are 16 B
+// per lane, and only one float4 of temporaries is live per lane.  The uniform switches are taken outside the element loops.
+constexpr int EPI_LD = 36;
+constexpr int EPI_WAVE_FLOATS = 32 * EPI_LD;
+
+__device__ __forceinline__ f32x4 act4(f32x4 v, int act) {
+    if (act == ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    } else if (act == ACT_GELU_ERF) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+    }
+    return v;
+}
+
+template <int TM, int TN, int WTM, int WTN>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int lane,
+                                              int slice, float* patch /* EPI_WAVE_FLOATS floats private to this wave */) {
+    const int col = lane & 31, rhalf = (lane >> 5) * 4;      // C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int rrow = lane >> 3, c4 = (lane & 7) * 4;         // read-back map: 8 rows x 8 float4 per pass
+    const bool split = p.splitk > 1;
+    float* part = split ? p.part + (long)slice * p.M * p.N : nullptr;
+    const bool vec = split ? ((p.N & 3) == 0)
+                           : (((p.N | p.ldc | p.c_coff) & 3) == 0 && (!p.R || ((p.ldr | p.r_coff) & 3) == 0));
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WTN + j * 32 + c4;
+        f32x4 bias = zero4(), sc = {1.f, 1.f, 1.f, 1.f}, sh = zero4();
+        if (!split) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (n + e < p.N) {
+                    if (p.bias) bias[e] = p.bias[n + e];
+                    if (p.scale) { sc[e] = p.scale[n + e]; sh[e] = p.shift[n + e]; }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + rhalf) * EPI_LD + col] = acc[i][j][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS ops complete in order; make it explicit
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int row = ps * 8 + rrow;
+                const int m = m0 + wm * WTM + i * 32 + row;
+                f32x4 v = *reinterpret_cast<const f32x4*>(patch + row * EPI_LD + c4);
+                if (m >= p.M || n >= p.N) continue;
+                if (split) {
+                    float* dst = part + (long)m * p.N + n;
+                    if (vec) *reinterpret_cast<f32x4*>(dst) = v;
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (n + e < p.N) dst[e] = v[e];
+                    }
+                    continue;
+                }
+                v = v + bias;
+                if (p.bbias) {
+                    const float* bp = p.bbias + (long)(m / p.bbias_rows) * p.N + n;
+                    if (vec) v = v + *reinterpret_cast<const f32x4*>(bp);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += bp[e];
+                    }
+                }
+                if (p.scale) v = v * sc + sh;
+                v = act4(v, p.act);
+                float* dst = p.C + (long)m * p.ldc + p.c_coff + n;
+                if (vec) {
+                    if (p.R) v = v + *reinterpret_cast<const f32x4*>(p.R + (long)m * p.ldr + p.r_coff + n);
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (n + e < p.N) {
+                            float t = v[e];
+                            if (p.R) t += p.R[(long)m * p.ldr + p.r_coff + n + e];
+                            dst[e] = t;
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();   // the patch is rewritten by the next tile
+        }
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int MODE>
 __global__ void __launch_bounds__(WM* WN * 64) gemm_f32_kernel(const GemmParams p) {
     constexpr int NT = WM * WN * 64;
@@ -38,7 +130,8 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_f32_kernel(const GemmParams 
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
     static_assert(PA >= 1 && PB >= 1 && TM >= 1 && TN >= 1, "tile too small for the thread count");
 
-    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_LD];
+    constexpr int SMEM_MAIN = (BM + BN) * LDS_LD, SMEM_EPI = WM * WN * EPI_WAVE_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI];
     float* As = smem;
     float* Bs = smem + BM * LDS_LD;
 
@@ -219,70 +312,198 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_f32_kernel(const GemmParams 
         }
     }
 
-    // ---- epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
-    const int col = lane & 31, rhalf = (lane >> 5) * 4;
-    if (p.splitk > 1) {
-        float* part = p.part + (long)slice * p.M * p.N;
+    gemm_epilogue<TM, TN, WTM, WTN>(p, acc, m0, n0, wm, wn, lane, slice, smem + wave * EPI_WAVE_FLOATS);
+}
+
+// =====================================================================================================================
+// gemm_split_kernel — the same contraction on the bf16 matrix cores with fp32-class accuracy.
+// Every fp32 operand x is split error-free into NP bf16 planes (x = x_h + x_m + x_l up to 2^-25 |x|: each plane is the
+// round-to-nearest bf16 of what the previous planes left over), the product is the sum of the plane products whose
+// magnitude is >= 2^-24 of the full product (NP = 3: hh, hm, mh, hl, lh, mm — 6 x v_mfma_f32_32x32x16_bf16), each exact in
+// the MFMA's fp32 accumulator.  6 bf16 MFMAs replace 8 fp32 MFMAs (k = 16 vs 2) at 16x the per-instruction rate: 2.67x the
+// fp32-MFMA peak.  A is split while it is staged (fp32 in HBM, no second copy); W is pre-split at load time ([NP][Npad][K]).
+// NP = 2 keeps hh, hm, mh (~2^-16 relative); NP = 1 is plain bf16 x bf16 -> fp32 (the bf16 throughput mode).
+// LDS: per plane [rows][40 bf16] (80-byte rows: conflict-free for the ds_read_b128 lane groups).
+// =====================================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int SLD = 40;   // bf16 elements per LDS row
+
+template <int NP>
+__device__ __forceinline__ void split4(const f32x4 v, bf16x4 (&out)[NP]) {
+    f32x4 r = v;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * WTN + j * 32 + col;
-            if (n >= p.N) continue;
+    for (int pl = 0; pl < NP; ++pl) {
+        bf16x4 h;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+        for (int e = 0; e < 4; ++e) h[e] = (__bf16)r[e];
+        out[pl] = h;
+        if (pl + 1 < NP) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
-                    if (m < p.M) part[(long)m * p.N + n] = acc[i][j][r];
-                }
-        }
-        return;
-    }
-    // Loads of a 32x32 tile's residual / per-image-bias values are issued together (16 independent loads in flight),
-    // the uniform epilogue switches are taken once per tile, not per element.
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WTN + j * 32 + col;
-        if (n >= p.N) continue;
-        const float bias = p.bias ? p.bias[n] : 0.f;
-        const float sc = p.scale ? p.scale[n] : 1.f;
-        const float sh = p.shift ? p.shift[n] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int mbase = m0 + wm * WTM + i * 32 + rhalf;
-            float rv[16], bb[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { rv[r] = 0.f; bb[r] = 0.f; }
-            if (p.R) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mbase + (r & 3) + 8 * (r >> 2);
-                    if (m < p.M) rv[r] = p.R[(long)m * p.ldr + p.r_coff + n];
-                }
-            }
-            if (p.bbias) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mbase + (r & 3) + 8 * (r >> 2);
-                    if (m < p.M) bb[r] = p.bbias[(long)(m / p.bbias_rows) * p.N + n];
-                }
-            }
-            float v[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = ((acc[i][j][r] + bias) + bb[r]) * sc + sh;
-            if (p.act == ACT_RELU) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
-            } else if (p.act == ACT_GELU_ERF) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = gelu_erf(v[r]);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mbase + (r & 3) + 8 * (r >> 2);
-                if (m < p.M) p.C[(long)m * p.ldc + p.c_coff + n] = v[r] + rv[r];
-            }
+            for (int e = 0; e < 4; ++e) r[e] = r[e] - (float)h[e];
         }
     }
+}
+
+template <int BM, int BN, int WM, int WN, int MODE, int NP>
+__global__ void __launch_bounds__(WM* WN * 64) gemm_split_kernel(const GemmParams p) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int RPP = NT / 8;           // A rows per pass (8 float4 per 32-float row)
+    constexpr int PA = BM / RPP;
+    constexpr int WRPP = NT / 4;          // W rows per pass (4 x 16-byte chunks per 32-bf16 row)
+    constexpr int PB = BN / WRPP;
+    constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+    static_assert(PA >= 1 && PB >= 1 && TM >= 1 && TN >= 1, "tile too small for the thread count");
+
+    constexpr int SMEM_MAIN = NP * (BM + BN) * SLD * 2, SMEM_EPI = WM * WN * EPI_WAVE_FLOATS * 4;   // bytes
+    __shared__ __attribute__((aligned(16))) char smem_raw[SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI];
+    __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);
+    __bf16* As = smem;                       // [NP][BM][SLD]
+    __bf16* Bs = smem + NP * BM * SLD;       // [NP][BN][SLD]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tilesN = (p.N + BN - 1) / BN;
+    int swz;
+    {
+        const int nwg = gridDim.x, orig = blockIdx.x;
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int ntiles = tilesN * ((p.M + BM - 1) / BM);
+    const int slice = swz / ntiles, tile = swz - slice * ntiles;
+    const int m0 = (tile / tilesN) * BM, n0 = (tile % tilesN) * BN;
+
+    const int kq = tid & 7, lrow = tid >> 3;
+    long a_base[PA];
+    int a_iy[PA], a_ix[PA];
+    bool a_ok[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int m = m0 + lrow + i * RPP;
+        a_ok[i] = m < p.M;
+        a_iy[i] = 0; a_ix[i] = 0;
+        if (MODE == GEMM_DENSE) {
+            a_base[i] = (long)m * p.lda;
+        } else {
+            const int hw = p.Hout * p.Wout;
+            const int b = m / hw, rem = m - b * hw;
+            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+            a_iy[i] = oy * p.stride - p.pad;
+            a_ix[i] = ox * p.stride - p.pad;
+            a_base[i] = (long)b * p.Hin * p.Win * p.lda + p.a_coff;
+        }
+    }
+    const int wc = tid & 3, wrow = tid >> 2;
+    const long wplane = (long)p.wp_rows * p.K;          // elements per W plane
+    const __bf16* wsrc = reinterpret_cast<const __bf16*>(p.Wp) + (long)(n0 + wrow) * p.K + wc * 8;
+
+    f32x4 ra[PA];
+    bf16x8 rb[NP][PB];
+
+    auto gload = [&](int kt) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int i = 0; i < PB; ++i)
+                rb[pl][i] = *reinterpret_cast<const bf16x8*>(wsrc + pl * wplane + (long)i * WRPP * p.K + k0);
+        if (MODE == GEMM_DENSE) {
+#pragma unroll
+            for (int i = 0; i < PA; ++i)
+                ra[i] = a_ok[i] ? *reinterpret_cast<const f32x4*>(p.A + a_base[i] + k0 + kq * 4) : zero4();
+        } else {
+            const int tap = k0 / p.Cin, ci0 = k0 - tap * p.Cin;
+            const int ky = tap / p.kw, kx = tap - ky * p.kw;
+            const int dy = ky * p.dil, dx = kx * p.dil;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
+                const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+                ra[i] = ok ? *reinterpret_cast<const f32x4*>(p.A + a_base[i] + ((long)iy * p.Win + ix) * p.lda + ci0 + kq * 4)
+                           : zero4();
+            }
+        }
+    };
+    auto lds_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            bf16x4 sp[NP];
+            split4<NP>(ra[i], sp);
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+                *reinterpret_cast<bf16x4*>(As + (pl * BM + lrow + i * RPP) * SLD + kq * 4) = sp[pl];
+        }
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int i = 0; i < PB; ++i)
+                *reinterpret_cast<bf16x8*>(Bs + (pl * BN + wrow + i * WRPP) * SLD + wc * 8) = rb[pl][i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk_all = p.K / BK;
+    const int kts = (nk_all + p.splitk - 1) / p.splitk;
+    const int kt0 = slice * kts, nk = min(nk_all, kt0 + kts);
+    // MFMA 32x32x16 bf16 operand map: lane l holds row (l & 31), k = 8 * (l >> 5) + j, j = 0..7
+    const __bf16* a_frag = As + (wm * WTM + (lane & 31)) * SLD + (lane >> 5) * 8;
+    const __bf16* b_frag = Bs + (wn * WTN + (lane & 31)) * SLD + (lane >> 5) * 8;
+
+    if (kt0 < nk) {
+        gload(kt0);
+        lds_store();
+    }
+    __syncthreads();
+    for (int kt = kt0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[NP][TM], bf[NP][TN];
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[pl][i] = *reinterpret_cast<const bf16x8*>(a_frag + (pl * BM + i * 32) * SLD + ks * 16);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[pl][j] = *reinterpret_cast<const bf16x8*>(b_frag + (pl * BN + j * 32) * SLD + ks * 16);
+            }
+            // smallest plane products first
+#pragma unroll
+            for (int sum = 2 * (NP - 1) > 2 ? 2 : 2 * (NP - 1); sum >= 0; --sum)
+#pragma unroll
+                for (int pa = 0; pa < NP; ++pa) {
+                    const int pb = sum - pa;
+                    if (pb < 0 || pb >= NP) continue;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa][i], bf[pb][j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        if (kt + 1 < nk) {
+            lds_store();
+            __syncthreads();
+        }
+    }
+    gemm_epilogue<TM, TN, WTM, WTN>(p, acc, m0, n0, wm, wn, lane, slice, reinterpret_cast<float*>(smem_raw) + wave * EPI_WAVE_FLOATS);
+}
+
+template <int BM, int BN, int WM, int WN, int NP>
+static hipError_t launch_split_cfg(const GemmParams& p, hipStream_t s) {
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.splitk;
+    dim3 grid(tiles), block(WM * WN * 64);
+    if (p.mode == GEMM_DENSE) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WM, WN, GEMM_DENSE, NP>), grid, block, 0, s, p);
+    else if (p.mode == GEMM_CONV_NHWC) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WM, WN, GEMM_CONV_NHWC, NP>), grid, block, 0, s, p);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
 }
 
 // diagnostic: back-to-back v_mfma_f32_32x32x2_f32 on register operands (4 independent accumulators per wave); lane 0 of
@@ -375,6 +596,22 @@ hipError_t launch_gemm(const GemmParams& p_in, const GemmPlan& pl, float* ws, hi
     p.part = ws;
     if (p.splitk > 1 && !ws) return hipErrorInvalidValue;
     hipError_t e;
+    if (p.planes > 0 && p.Wp && (p.mode == GEMM_DENSE || p.mode == GEMM_CONV_NHWC)) {
+        // split-bf16 path: tile choice by the same plan (64x64 / 128x64 / 128x128 families)
+        if (p.planes == 3) {
+            if (pl.cfg == 2) e = launch_split_cfg<64, 64, 2, 2, 3>(p, s);
+            else if (pl.cfg == 1) e = launch_split_cfg<128, 64, 2, 2, 3>(p, s);
+            else e = launch_split_cfg<128, 128, 2, 2, 3>(p, s);
+        } else if (p.planes == 2) {
+            if (pl.cfg == 2) e = launch_split_cfg<64, 64, 2, 2, 2>(p, s);
+            else if (pl.cfg == 1) e = launch_split_cfg<128, 64, 2, 2, 2>(p, s);
+            else e = launch_split_cfg<128, 128, 2, 2, 2>(p, s);
+        } else {
+            if (pl.cfg == 2) e = launch_split_cfg<64, 64, 2, 2, 1>(p, s);
+            else if (pl.cfg == 1) e = launch_split_cfg<128, 64, 2, 2, 1>(p, s);
+            else e = launch_split_cfg<128, 128, 2, 2, 1>(p, s);
+        }
+    } else
     if (pl.cfg == 0) e = launch_cfg<128, 128, 2, 2>(p, s);
     else if (pl.cfg == 1) e = launch_cfg<128, 64, 2, 2>(p, s);
     else if (pl.cfg == 3) e = launch_cfg<128, 128, 2, 4>(p, s);

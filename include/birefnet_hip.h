@@ -40,7 +40,14 @@ enum {
 };
 
 typedef enum { BRN_MEM_HOST = 0, BRN_MEM_DEVICE = 1 } brn_mem;
-typedef enum { BRN_F32 = 0 } brn_dtype; /* arithmetic type of the path (reference: DType::F32, infer_image.rs:26) */
+/* Arithmetic of the contraction kernels (everything else — LayerNorm, softmax, epilogues, storage — is fp32; the
+ * reference runs DType::F32, infer_image.rs:26):
+ *   BRN_F32            fp32 operands on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32), exact fmaf chain
+ *   BRN_F32_SPLIT3     fp32 operands split error-free into 3 bf16 planes, 6 bf16 MFMAs per product, fp32 accumulate:
+ *                      fp32-class accuracy (dropped terms < 2^-24 of a product) at 2.67x the fp32-MFMA rate
+ *   BRN_F32_SPLIT2     2 planes, 3 MFMAs: ~2^-16 relative per product
+ *   BRN_BF16_OPERANDS  operands rounded to bf16, fp32 accumulate (the bf16 throughput mode; parity is informational) */
+typedef enum { BRN_F32 = 0, BRN_F32_SPLIT3 = 1, BRN_F32_SPLIT2 = 2, BRN_BF16_OPERANDS = 3 } brn_dtype;
 
 /* D1 of SURVEY.md §8: what DeformConvASPP::forward computes.
  * REFERENCE_CPU = aspp.rs:183-185 (offset/modulator discarded, regular_conv(x)) — the graded parity target.
@@ -192,7 +199,8 @@ brn_status brn_deform_conv2d_forward(const float* x, int B, int C, int H, int W,
 
 /* ---- diagnostics ---------------------------------------------------------------------------------------- */
 /* Times `iters` launches of the dense gemm_f32 kernel on random device data (M x K times N x K^T).  tile_cfg: -1 = the
- * library's own plan, 0 = 128x128, 1 = 128x64, 2 = 64x64 block tile; splitk only with tile_cfg >= 0.  Tuning aid. */
+ * library's own plan, 0 = 128x128, 1 = 128x64, 2 = 64x64 block tile; splitk only with tile_cfg >= 0; add 1000*planes
+ * (planes 1..3) for the split-bf16 kernel (1999/2999/3999 = library plan with 1/2/3 planes).  Tuning aid. */
 brn_status brn_gemm_microbench(int M, int N, int K, int tile_cfg, int splitk, int iters, int device_ordinal,
                                float* ms_per_launch);
 
