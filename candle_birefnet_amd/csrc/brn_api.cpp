@@ -647,6 +647,7 @@ brn_status brn_gemm_microbench(int M, int N, int K, int tile_cfg, int splitk, in
         GemmParams p{};
         p.A = dA; p.W = dW; p.C = dC; p.M = M; p.N = N; p.K = K; p.mode = GEMM_DENSE; p.lda = K; p.ldc = N; p.bbias_rows = 1;
         p.Wp = gw.wp; p.planes = gw.planes; p.wp_rows = gw.wp_rows;
+        if (const char* ab = getenv("BRN_GEMM_ABLATE")) p.abl = atoi(ab);
         hipEvent_t e0, e1;
         BRN_HIP(hipEventCreate(&e0)); BRN_HIP(hipEventCreate(&e1));
         for (int i = 0; i < 3; ++i) BRN_HIP(launch_gemm(p, pl, ws, nullptr));

@@ -41,6 +41,7 @@ struct GemmParams {
     const void* Wp; int planes; int wp_rows;
     // split-K (filled by launch_gemm from the plan): slices write raw partials to part[slice][M][N]
     int splitk; float* part;
+    int abl;   // diagnostics only (brn_gemm_microbench): 1 = no global loads in the K loop, 2 = no LDS staging, 4 = no fragment reads / MFMA
 };
 
 struct GemmPlan { int cfg; int splitk; size_t ws_floats; };   // cfg: 0 = 128x128, 1 = 128x64, 2 = 64x64 block tile

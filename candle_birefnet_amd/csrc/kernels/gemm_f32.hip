@@ -30,6 +30,18 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
+// tile id -> (m tile, n tile): N is walked in groups of GN tile columns, M fastest-but-one inside a group, so that while an XCD
+// marches down M the GN weight panels of the group stay in its 4 MiB L2 and every A panel is fetched once per group
+// (the split-bf16 kernels are bound by L2-miss traffic, not by the matrix pipe).
+__device__ __forceinline__ void tile_coords(int tile, int tilesM, int tilesN, int& tm, int& tn) {
+    constexpr int GN = 4;
+    const int per_group = tilesM * GN;
+    const int g = tile / per_group, r = tile - g * per_group;
+    const int gw = min(GN, tilesN - g * GN);
+    tm = r / gw;
+    tn = g * GN + (r - tm * gw);
+}
+
 // ---- epilogue shared by the fp32-MFMA and the split-bf16 kernels (same 32x32 C/D register map) ----
 // Each 32x32 accumulator tile is transposed through a wave-private LDS patch (rows of 36 floats) so that the global side
 // is row-major float4: 8 lanes cover one 128-byte row segment, residual / per-image-bias loads and the stores are 16 B
@@ -150,7 +162,9 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_f32_kernel(const GemmParams 
     // split-K: grid = tiles x splitk; slice s of a tile contracts k-tiles [s*kts, (s+1)*kts) and writes raw partial sums
     const int ntiles = tilesN * ((p.M + BM - 1) / BM);
     const int slice = swz / ntiles, tile = swz - slice * ntiles;
-    const int m0 = (tile / tilesN) * BM, n0 = (tile % tilesN) * BN;
+    int tile_m, tile_n;
+    tile_coords(tile, (p.M + BM - 1) / BM, tilesN, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int kq = tid & 7, lrow = tid >> 3;
 
@@ -372,7 +386,9 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_split_kernel(const GemmParam
     }
     const int ntiles = tilesN * ((p.M + BM - 1) / BM);
     const int slice = swz / ntiles, tile = swz - slice * ntiles;
-    const int m0 = (tile / tilesN) * BM, n0 = (tile % tilesN) * BN;
+    int tile_m, tile_n;
+    tile_coords(tile, (p.M + BM - 1) / BM, tilesN, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int kq = tid & 7, lrow = tid >> 3;
     long a_base[PA];
@@ -398,20 +414,22 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_split_kernel(const GemmParam
     const long wplane = (long)p.wp_rows * p.K;          // elements per W plane
     const __bf16* wsrc = reinterpret_cast<const __bf16*>(p.Wp) + (long)(n0 + wrow) * p.K + wc * 8;
 
-    f32x4 ra[PA];
-    bf16x8 rb[NP][PB];
+    // two staging register sets: tile kt+2 is already in flight while tile kt is multiplied (bytes in flight per CU, not
+    // bandwidth, bound this kernel: a bf16-rate K tile lasts a few hundred cycles, an L2/HBM round trip ~1-2 thousand)
+    f32x4 ra[2][PA];
+    bf16x8 rb[2][NP][PB];
 
-    auto gload = [&](int kt) {
+    auto gload = [&](int kt, f32x4 (&qa)[PA], bf16x8 (&qb)[NP][PB]) {
         const int k0 = kt * BK;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
             for (int i = 0; i < PB; ++i)
-                rb[pl][i] = *reinterpret_cast<const bf16x8*>(wsrc + pl * wplane + (long)i * WRPP * p.K + k0);
+                qb[pl][i] = *reinterpret_cast<const bf16x8*>(wsrc + pl * wplane + (long)i * WRPP * p.K + k0);
         if (MODE == GEMM_DENSE) {
 #pragma unroll
             for (int i = 0; i < PA; ++i)
-                ra[i] = a_ok[i] ? *reinterpret_cast<const f32x4*>(p.A + a_base[i] + k0 + kq * 4) : zero4();
+                qa[i] = a_ok[i] ? *reinterpret_cast<const f32x4*>(p.A + a_base[i] + k0 + kq * 4) : zero4();
         } else {
             const int tap = k0 / p.Cin, ci0 = k0 - tap * p.Cin;
             const int ky = tap / p.kw, kx = tap - ky * p.kw;
@@ -420,16 +438,16 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_split_kernel(const GemmParam
             for (int i = 0; i < PA; ++i) {
                 const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
                 const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-                ra[i] = ok ? *reinterpret_cast<const f32x4*>(p.A + a_base[i] + ((long)iy * p.Win + ix) * p.lda + ci0 + kq * 4)
+                qa[i] = ok ? *reinterpret_cast<const f32x4*>(p.A + a_base[i] + ((long)iy * p.Win + ix) * p.lda + ci0 + kq * 4)
                            : zero4();
             }
         }
     };
-    auto lds_store = [&]() {
+    auto lds_store = [&](const f32x4 (&qa)[PA], const bf16x8 (&qb)[NP][PB]) {
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             bf16x4 sp[NP];
-            split4<NP>(ra[i], sp);
+            split4<NP>(qa[i], sp);
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
                 *reinterpret_cast<bf16x4*>(As + (pl * BM + lrow + i * RPP) * SLD + kq * 4) = sp[pl];
@@ -438,7 +456,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_split_kernel(const GemmParam
         for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
             for (int i = 0; i < PB; ++i)
-                *reinterpret_cast<bf16x8*>(Bs + (pl * BN + wrow + i * WRPP) * SLD + wc * 8) = rb[pl][i];
+                *reinterpret_cast<bf16x8*>(Bs + (pl * BN + wrow + i * WRPP) * SLD + wc * 8) = qb[pl][i];
     };
 
     f32x16 acc[TM][TN];
@@ -456,13 +474,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_split_kernel(const GemmParam
     const __bf16* a_frag = As + (wm * WTM + (lane & 31)) * SLD + (lane >> 5) * 8;
     const __bf16* b_frag = Bs + (wn * WTN + (lane & 31)) * SLD + (lane >> 5) * 8;
 
-    if (kt0 < nk) {
-        gload(kt0);
-        lds_store();
-    }
-    __syncthreads();
-    for (int kt = kt0; kt < nk; ++kt) {
-        if (kt + 1 < nk) gload(kt + 1);
+    auto compute = [&]() {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 af[NP][TM], bf[NP][TN];
@@ -487,13 +499,230 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_split_kernel(const GemmParam
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa][i], bf[pb][j], acc[i][j], 0, 0, 0);
                 }
         }
-        __syncthreads();
-        if (kt + 1 < nk) {
-            lds_store();
-            __syncthreads();
-        }
+    };
+
+    if (kt0 < nk) {
+        gload(kt0, ra[0], rb[0]);
+        if (kt0 + 1 < nk) gload(kt0 + 1, ra[1], rb[1]);
+        lds_store(ra[0], rb[0]);
     }
+    __syncthreads();
+    // body for one K tile whose successor sits in register set NXT; the set just consumed (CUR) is refilled 2 tiles ahead
+#define BRN_SPLIT_STEP(KT, CUR, NXT)                                  \
+    {                                                                 \
+        if ((KT) + 2 < nk && !(p.abl & 1)) gload((KT) + 2, ra[CUR], rb[CUR]);         \
+        if (!(p.abl & 4)) compute();                                  \
+        __syncthreads();                                              \
+        if ((KT) + 1 < nk) {                                          \
+            if (!(p.abl & 2)) lds_store(ra[NXT], rb[NXT]);            \
+            __syncthreads();                                          \
+        }                                                             \
+    }
+    for (int kt = kt0; kt < nk; kt += 2) {
+        BRN_SPLIT_STEP(kt, 0, 1)
+        if (kt + 1 < nk) BRN_SPLIT_STEP(kt + 1, 1, 0)
+    }
+#undef BRN_SPLIT_STEP
     gemm_epilogue<TM, TN, WTM, WTN>(p, acc, m0, n0, wm, wn, lane, slice, reinterpret_cast<float*>(smem_raw) + wave * EPI_WAVE_FLOATS);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// gemm_split_ws_kernel — warp-specialised form of gemm_split_kernel for the 128x128 tile: 8 waves, two per SIMD.
+// Waves 0-3 (consumers) own the 2x2 grid of 64x64 sub-tiles: fragment reads + MFMA only.  Waves 4-7 (producers) stage:
+// global loads four K tiles ahead (two register sets), operand split, LDS writes into a ring of NBUF = 3 K-tile buffers,
+// two tiles ahead of the consumers.  ONE workgroup barrier per K tile.  Because tile kt+1 is already complete while tile kt
+// is multiplied, a consumer prefetches the next tile's first fragments before the barrier and double-buffers fragments in
+// registers: at bf16 MFMA rates an exposed LDS read (~250 cycles) per 32-deep K tile (768 MFMA cycles) was a third of the
+// loop (measured by ablation: staging and MFMA phases added up, then the fragment-read stall did).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int MODE, int NP>
+__global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) {
+    constexpr int BM = 128, BN = 128, WTM = 64, WTN = 64, TM = 2, TN = 2;
+    constexpr int NBUF = 2;                         // 2 x NP x 20 KB: two workgroups per CU at NP <= 2 (a 3-deep ring was slower: 1 WG/CU exposes each tile's prologue + epilogue)
+    constexpr int RPP = 32, PA = BM / RPP;          // producers: 256 threads, 8 float4 per 32-float row
+    constexpr int WRPP = 64, PB = BN / WRPP;        // 4 x 16-byte chunks per 32-bf16 row
+    constexpr int BUF = NP * (BM + BN) * SLD;       // bf16 elements per LDS buffer
+    constexpr int SMEM_MAIN = NBUF * BUF * 2, SMEM_EPI = 4 * EPI_WAVE_FLOATS * 4;   // bytes
+    __shared__ __attribute__((aligned(16))) char smem_raw[SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI];
+    __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool producer = wave >= 4;
+    const int tilesN = (p.N + BN - 1) / BN;
+    int swz;
+    {
+        const int nwg = gridDim.x, orig = blockIdx.x;
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int ntiles = tilesN * ((p.M + BM - 1) / BM);
+    const int slice = swz / ntiles, tile = swz - slice * ntiles;
+    int tile_m, tile_n;
+    tile_coords(tile, (p.M + BM - 1) / BM, tilesN, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nk_all = p.K / BK;
+    const int kts = (nk_all + p.splitk - 1) / p.splitk;
+    const int kt0 = slice * kts, nk = min(nk_all, kt0 + kts);
+    const int nt = nk > kt0 ? nk - kt0 : 0;         // K tiles of this slice; local tile index t = kt - kt0
+
+    if (producer) {
+        const int pt = tid - 256;
+        const int kq = pt & 7, lrow = pt >> 3;
+        long a_base[PA];
+        int a_iy[PA], a_ix[PA];
+        bool a_ok[PA];
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int m = m0 + lrow + i * RPP;
+            a_ok[i] = m < p.M;
+            a_iy[i] = 0; a_ix[i] = 0;
+            if (MODE == GEMM_DENSE) {
+                a_base[i] = (long)m * p.lda;
+            } else {
+                const int hw = p.Hout * p.Wout;
+                const int b = m / hw, rem = m - b * hw;
+                const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+                a_iy[i] = oy * p.stride - p.pad;
+                a_ix[i] = ox * p.stride - p.pad;
+                a_base[i] = (long)b * p.Hin * p.Win * p.lda + p.a_coff;
+            }
+        }
+        const int wc = pt & 3, wrow = pt >> 2;
+        const long wplane = (long)p.wp_rows * p.K;
+        const __bf16* wsrc = reinterpret_cast<const __bf16*>(p.Wp) + (long)(n0 + wrow) * p.K + wc * 8;
+        f32x4 ra[2][PA];
+        bf16x8 rb[2][NP][PB];
+        auto gload = [&](int t, f32x4 (&qa)[PA], bf16x8 (&qb)[NP][PB]) {
+            const int k0 = (kt0 + t) * BK;
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                for (int i = 0; i < PB; ++i)
+                    qb[pl][i] = *reinterpret_cast<const bf16x8*>(wsrc + pl * wplane + (long)i * WRPP * p.K + k0);
+            if (MODE == GEMM_DENSE) {
+#pragma unroll
+                for (int i = 0; i < PA; ++i)
+                    qa[i] = a_ok[i] ? *reinterpret_cast<const f32x4*>(p.A + a_base[i] + k0 + kq * 4) : zero4();
+            } else {
+                const int tap = k0 / p.Cin, ci0 = k0 - tap * p.Cin;
+                const int ky = tap / p.kw, kx = tap - ky * p.kw;
+                const int dy = ky * p.dil, dx = kx * p.dil;
+#pragma unroll
+                for (int i = 0; i < PA; ++i) {
+                    const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
+                    const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+                    qa[i] = ok ? *reinterpret_cast<const f32x4*>(p.A + a_base[i] + ((long)iy * p.Win + ix) * p.lda + ci0 + kq * 4)
+                               : zero4();
+                }
+            }
+        };
+        auto lds_store = [&](int t, const f32x4 (&qa)[PA], const bf16x8 (&qb)[NP][PB]) {
+            __bf16* As = smem + (t % NBUF) * BUF;
+            __bf16* Bs = As + NP * BM * SLD;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                bf16x4 sp[NP];
+                split4<NP>(qa[i], sp);
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+                    *reinterpret_cast<bf16x4*>(As + (pl * BM + lrow + i * RPP) * SLD + kq * 4) = sp[pl];
+            }
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                for (int i = 0; i < PB; ++i)
+                    *reinterpret_cast<bf16x8*>(Bs + (pl * BN + wrow + i * WRPP) * SLD + wc * 8) = qb[pl][i];
+        };
+        constexpr int AHEAD = NBUF - 1;     // LDS tiles the producers run ahead of the consumers
+        // prologue: LDS tiles 0 .. AHEAD-1 stored, register sets hold the next two tiles
+        if (nt > 0) gload(0, ra[0], rb[0]);
+        if (nt > 1) gload(1, ra[1], rb[1]);
+        if (nt > 0 && !(p.abl & 2)) lds_store(0, ra[0], rb[0]);
+        if (nt > 2) gload(2, ra[0], rb[0]);
+        if (AHEAD > 1) {
+            if (nt > 1 && !(p.abl & 2)) lds_store(1, ra[1], rb[1]);
+            if (nt > 3) gload(3, ra[1], rb[1]);
+        }
+        __syncthreads();
+        // step t: store tile t+AHEAD (register set (t+AHEAD)&1), refill that set with tile t+AHEAD+2
+#define BRN_PROD_STEP(T, SET)                                                              \
+        {                                                                                  \
+            if ((T) + AHEAD < nt) {                                                        \
+                if (!(p.abl & 2)) lds_store((T) + AHEAD, ra[SET], rb[SET]);                \
+                if ((T) + AHEAD + 2 < nt && !(p.abl & 1)) gload((T) + AHEAD + 2, ra[SET], rb[SET]); \
+            }                                                                              \
+            __syncthreads();                                                               \
+        }
+        for (int t = 0; t < nt; t += 2) {
+            BRN_PROD_STEP(t, AHEAD & 1)
+            if (t + 1 < nt) BRN_PROD_STEP(t + 1, (AHEAD + 1) & 1)
+        }
+#undef BRN_PROD_STEP
+        return;
+    }
+
+    // ---- consumers ----
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int a_off = (wm * WTM + (lane & 31)) * SLD + (lane >> 5) * 8;
+    const int b_off = NP * BM * SLD + (wn * WTN + (lane & 31)) * SLD + (lane >> 5) * 8;
+    auto read_frags = [&](int t, int ks, bf16x8 (&af)[NP][TM], bf16x8 (&bf)[NP][TN]) {
+        const __bf16* buf = smem + (t % NBUF) * BUF;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[pl][i] = *reinterpret_cast<const bf16x8*>(buf + a_off + (pl * BM + i * 32) * SLD + ks * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[pl][j] = *reinterpret_cast<const bf16x8*>(buf + b_off + (pl * BN + j * 32) * SLD + ks * 16);
+        }
+    };
+    auto mfma_all = [&](const bf16x8 (&af)[NP][TM], const bf16x8 (&bf)[NP][TN]) {
+        // smallest plane products first
+#pragma unroll
+        for (int sum = 2 * (NP - 1) > 2 ? 2 : 2 * (NP - 1); sum >= 0; --sum)
+#pragma unroll
+            for (int pa = 0; pa < NP; ++pa) {
+                const int pb = sum - pa;
+                if (pb < 0 || pb >= NP) continue;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa][i], bf[pb][j], acc[i][j], 0, 0, 0);
+            }
+    };
+    bf16x8 fa0[NP][TM], fb0[NP][TN], fa1[NP][TM], fb1[NP][TN];
+    __syncthreads();   // prologue barrier: LDS tiles 0 .. AHEAD-1 are complete
+    constexpr bool XPREFETCH = NBUF >= 3;   // tile t+1 is complete during step t only with a 3-deep ring
+    if (nt > 0 && !(p.abl & 4)) read_frags(0, 0, fa0, fb0);
+    for (int t = 0; t < nt; ++t) {
+        if (!(p.abl & 4)) {
+            read_frags(t, 1, fa1, fb1);
+            mfma_all(fa0, fb0);
+            if (XPREFETCH && t + 1 < nt) read_frags(t + 1, 0, fa0, fb0);
+            mfma_all(fa1, fb1);
+        }
+        __syncthreads();
+        if (!XPREFETCH && t + 1 < nt && !(p.abl & 4)) read_frags(t + 1, 0, fa0, fb0);
+    }
+    // producers have left; the staging LDS is free for the epilogue patches (all LDS reads retired by the last barrier)
+    gemm_epilogue<TM, TN, WTM, WTN>(p, acc, m0, n0, wm, wn, lane, slice, reinterpret_cast<float*>(smem_raw) + wave * EPI_WAVE_FLOATS);
+}
+
+template <int NP>
+static hipError_t launch_split_ws(const GemmParams& p, hipStream_t s) {
+    const int tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128) * p.splitk;
+    dim3 grid(tiles), block(512);
+    if (p.mode == GEMM_DENSE) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, NP>), grid, block, 0, s, p);
+    else if (p.mode == GEMM_CONV_NHWC) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_CONV_NHWC, NP>), grid, block, 0, s, p);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
 }
 
 template <int BM, int BN, int WM, int WN, int NP>
@@ -597,8 +826,10 @@ hipError_t launch_gemm(const GemmParams& p_in, const GemmPlan& pl, float* ws, hi
     if (p.splitk > 1 && !ws) return hipErrorInvalidValue;
     hipError_t e;
     if (p.planes > 0 && p.Wp && (p.mode == GEMM_DENSE || p.mode == GEMM_CONV_NHWC)) {
-        // split-bf16 path: tile choice by the same plan (64x64 / 128x64 / 128x128 families)
-        if (p.planes == 3) {
+        // split-bf16 path: tile choice by the same plan (64x64 / 128x64 / 128x128 families); the 128x128 tile runs
+        // warp-specialised
+        if (pl.cfg == 6 || pl.cfg == 0 || pl.cfg == 3 || pl.cfg == 4 || pl.cfg == 5) e = p.planes == 3 ? launch_split_ws<3>(p, s) : (p.planes == 2 ? launch_split_ws<2>(p, s) : launch_split_ws<1>(p, s));
+        else if (p.planes == 3) {
             if (pl.cfg == 2) e = launch_split_cfg<64, 64, 2, 2, 3>(p, s);
             else if (pl.cfg == 1) e = launch_split_cfg<128, 64, 2, 2, 3>(p, s);
             else e = launch_split_cfg<128, 128, 2, 2, 3>(p, s);
