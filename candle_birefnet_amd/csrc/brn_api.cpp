@@ -516,7 +516,11 @@ brn_status brn_window_attention_forward(const float* x, int B, int H, int W, int
         bk.qkv = make_linear(own, qkv_w, qkv_b, 3 * C, C);
         bk.proj = make_linear(own, proj_w, proj_b, C, C);
         (void)s_qw; (void)s_qb; (void)s_pw; (void)s_pb; (void)s_t;
-        bk.rel_table = own.upload(rel_table, (size_t)T * heads);
+        {
+            std::vector<float> tt((size_t)T * heads);
+            for (int t = 0; t < T; ++t) for (int h = 0; h < heads; ++h) tt[(size_t)h * T + t] = rel_table[(size_t)t * heads + h];
+            bk.rel_table = own.upload(tt);
+        }
         Staging st(stream, loc);
         const float* dx = st.in(x, (size_t)B * H * W * C);
         float* dy = st.out(y, (size_t)B * H * W * C);

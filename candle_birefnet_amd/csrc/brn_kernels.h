@@ -66,7 +66,7 @@ hipError_t launch_layernorm(const LayerNormParams& p, hipStream_t s);
 struct WindowAttnParams {
     const float* qkv;     // [B, H, W, 3C] natural token order (q | k | v, heads-major inside each, swin.rs:218)
     const float* qkv_bias;// [3C]  (q/k/v of a zero pad token)
-    const float* rel_table;// relative_position_bias_table [(2*12-1)^2][heads] (swin.rs:138-141); cached_bias (swin.rs:147-152) is never built
+    const float* rel_table;// relative_position_bias_table (swin.rs:138-141) transposed to [heads][(2*12-1)^2]; cached_bias (swin.rs:147-152) is never built
     float* out;           // [B, H, W, C]
     int B, H, W, C, heads;
     int Hp, Wp;           // padded canvas (multiples of 12)

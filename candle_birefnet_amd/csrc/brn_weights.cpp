@@ -224,7 +224,12 @@ void build_swin_weights(const WeightTable& wt, const std::string& pre, const brn
             bk.fc1.act = ACT_GELU_ERF;                                  // swin.rs:105
             bk.fc2 = get_linear(wt, bp + "mlp.fc2", C, hidden, true, own);
             const float* table = wt.get(bp + "attn.relative_position_bias_table", {T, heads})->data;
-            bk.rel_table = own.upload(table, (size_t)T * heads);   // indexed in-kernel: (qi-ki+ws-1)*(2ws-1) + (qj-kj+ws-1), swin.rs:182-184
+            {   // [T][heads] -> [heads][T] so a workgroup reads its head's column contiguously; indexed in-kernel by
+                // (qi-ki+ws-1)*(2ws-1) + (qj-kj+ws-1) (swin.rs:182-184)
+                std::vector<float> tt((size_t)T * heads);
+                for (int t = 0; t < T; ++t) for (int h = 0; h < heads; ++h) tt[(size_t)h * T + t] = table[(size_t)t * heads + h];
+                bk.rel_table = own.upload(tt);
+            }
         }
         st.has_down = i < 3;
         if (st.has_down) {

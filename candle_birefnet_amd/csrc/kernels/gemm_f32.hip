@@ -22,6 +22,16 @@ namespace brn {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+// a load the optimiser may not sink under the predicate that later selects its value: hipcc turns `ok ? *p : 0` (and
+// `t = *p; ok ? t : 0`) into an exec-branch around the load, and then waits vmcnt(0) before the first use of ANY staged
+// register in the loop, draining the prefetched K tiles every iteration.
+// So: load from a clamped (always valid) address, remember a 1.0 / 0.0 mask, and zero the value arithmetically when the
+// staged registers are consumed (x * mask at the LDS store) — never a select at the load, never arithmetic at the load
+// (that would wait for the data right there).
+__device__ __forceinline__ f32x4 load4_masked(const float* ptr, bool ok, float& mask) {
+    mask = ok ? 1.0f : 0.0f;
+    return *reinterpret_cast<const f32x4*>(ptr);
+}
 
 constexpr int BK = 32;
 constexpr int LDS_LD = 36;
@@ -194,6 +204,9 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_f32_kernel(const GemmParams 
     const float* wrow = p.W + (long)(n0 + lrow) * p.K + kq * 4;
 
     f32x4 ra[PA], rb[PB];
+    float am[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) am[i] = 1.0f;
 
     auto gload = [&](int kt) {
         const int k0 = kt * BK;
@@ -202,8 +215,9 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_f32_kernel(const GemmParams 
         if (MODE == GEMM_DENSE) {
 #pragma unroll
             for (int i = 0; i < PA; ++i)
-                ra[i] = a_ok[i] ? *reinterpret_cast<const f32x4*>(p.A + a_base[i] + k0 + kq * 4)
-                                : zero4();
+                {   // unconditional load from a clamped address + select: no exec branch, so the compiler keeps counted vmcnt waits
+                    ra[i] = load4_masked(p.A + (a_ok[i] ? a_base[i] : 0) + k0 + kq * 4, a_ok[i], am[i]);
+                }
         } else if (MODE == GEMM_CONV_NHWC) {
             const int tap = k0 / p.Cin, ci0 = k0 - tap * p.Cin;
             const int ky = tap / p.kw, kx = tap - ky * p.kw;
@@ -212,9 +226,8 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_f32_kernel(const GemmParams 
             for (int i = 0; i < PA; ++i) {
                 const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
                 const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-                ra[i] = ok ? *reinterpret_cast<const f32x4*>(p.A + a_base[i] + ((long)iy * p.Win + ix) * p.lda +
-                                                              ci0 + kq * 4)
-                           : zero4();
+                const long off = ok ? a_base[i] + ((long)iy * p.Win + ix) * p.lda + ci0 : (long)p.a_coff;
+                ra[i] = load4_masked(p.A + off + kq * 4, ok, am[i]);
             }
         } else if (MODE == GEMM_GATHER_NCHW) {
             const int khw = p.kh * p.kw;
@@ -267,7 +280,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_f32_kernel(const GemmParams 
     auto lds_store = [&]() {
 #pragma unroll
         for (int i = 0; i < PA; ++i)
-            *reinterpret_cast<f32x4*>(As + (lrow + i * RPP) * LDS_LD + kq * 4) = ra[i];
+            *reinterpret_cast<f32x4*>(As + (lrow + i * RPP) * LDS_LD + kq * 4) = ra[i] * am[i];
 #pragma unroll
         for (int i = 0; i < PB; ++i)
             *reinterpret_cast<f32x4*>(Bs + (lrow + i * RPP) * LDS_LD + kq * 4) = rb[i];
@@ -418,8 +431,9 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_split_kernel(const GemmParam
     // bandwidth, bound this kernel: a bf16-rate K tile lasts a few hundred cycles, an L2/HBM round trip ~1-2 thousand)
     f32x4 ra[2][PA];
     bf16x8 rb[2][NP][PB];
+    float am[2][PA];
 
-    auto gload = [&](int kt, f32x4 (&qa)[PA], bf16x8 (&qb)[NP][PB]) {
+    auto gload = [&](int kt, f32x4 (&qa)[PA], bf16x8 (&qb)[NP][PB], float (&qm)[PA]) {
         const int k0 = kt * BK;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
@@ -429,7 +443,9 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_split_kernel(const GemmParam
         if (MODE == GEMM_DENSE) {
 #pragma unroll
             for (int i = 0; i < PA; ++i)
-                qa[i] = a_ok[i] ? *reinterpret_cast<const f32x4*>(p.A + a_base[i] + k0 + kq * 4) : zero4();
+                {
+                    qa[i] = load4_masked(p.A + (a_ok[i] ? a_base[i] : 0) + k0 + kq * 4, a_ok[i], qm[i]);
+                }
         } else {
             const int tap = k0 / p.Cin, ci0 = k0 - tap * p.Cin;
             const int ky = tap / p.kw, kx = tap - ky * p.kw;
@@ -438,16 +454,16 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_split_kernel(const GemmParam
             for (int i = 0; i < PA; ++i) {
                 const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
                 const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-                qa[i] = ok ? *reinterpret_cast<const f32x4*>(p.A + a_base[i] + ((long)iy * p.Win + ix) * p.lda + ci0 + kq * 4)
-                           : zero4();
+                const long off = ok ? a_base[i] + ((long)iy * p.Win + ix) * p.lda + ci0 : (long)p.a_coff;
+                qa[i] = load4_masked(p.A + off + kq * 4, ok, qm[i]);
             }
         }
     };
-    auto lds_store = [&](const f32x4 (&qa)[PA], const bf16x8 (&qb)[NP][PB]) {
+    auto lds_store = [&](const f32x4 (&qa)[PA], const bf16x8 (&qb)[NP][PB], const float (&qm)[PA]) {
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             bf16x4 sp[NP];
-            split4<NP>(qa[i], sp);
+            split4<NP>(qa[i] * qm[i], sp);
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
                 *reinterpret_cast<bf16x4*>(As + (pl * BM + lrow + i * RPP) * SLD + kq * 4) = sp[pl];
@@ -502,19 +518,19 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_split_kernel(const GemmParam
     };
 
     if (kt0 < nk) {
-        gload(kt0, ra[0], rb[0]);
-        if (kt0 + 1 < nk) gload(kt0 + 1, ra[1], rb[1]);
-        lds_store(ra[0], rb[0]);
+        gload(kt0, ra[0], rb[0], am[0]);
+        if (kt0 + 1 < nk) gload(kt0 + 1, ra[1], rb[1], am[1]);
+        lds_store(ra[0], rb[0], am[0]);
     }
     __syncthreads();
     // body for one K tile whose successor sits in register set NXT; the set just consumed (CUR) is refilled 2 tiles ahead
 #define BRN_SPLIT_STEP(KT, CUR, NXT)                                  \
     {                                                                 \
-        if ((KT) + 2 < nk && !(p.abl & 1)) gload((KT) + 2, ra[CUR], rb[CUR]);         \
+        if ((KT) + 2 < nk && !(p.abl & 1)) gload((KT) + 2, ra[CUR], rb[CUR], am[CUR]);         \
         if (!(p.abl & 4)) compute();                                  \
         __syncthreads();                                              \
         if ((KT) + 1 < nk) {                                          \
-            if (!(p.abl & 2)) lds_store(ra[NXT], rb[NXT]);            \
+            if (!(p.abl & 2)) lds_store(ra[NXT], rb[NXT], am[NXT]);            \
             __syncthreads();                                          \
         }                                                             \
     }
@@ -592,7 +608,8 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
         const __bf16* wsrc = reinterpret_cast<const __bf16*>(p.Wp) + (long)(n0 + wrow) * p.K + wc * 8;
         f32x4 ra[2][PA];
         bf16x8 rb[2][NP][PB];
-        auto gload = [&](int t, f32x4 (&qa)[PA], bf16x8 (&qb)[NP][PB]) {
+        float am[2][PA];
+        auto gload = [&](int t, f32x4 (&qa)[PA], bf16x8 (&qb)[NP][PB], float (&qm)[PA]) {
             const int k0 = (kt0 + t) * BK;
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
@@ -602,7 +619,9 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
             if (MODE == GEMM_DENSE) {
 #pragma unroll
                 for (int i = 0; i < PA; ++i)
-                    qa[i] = a_ok[i] ? *reinterpret_cast<const f32x4*>(p.A + a_base[i] + k0 + kq * 4) : zero4();
+                    {
+                    qa[i] = load4_masked(p.A + (a_ok[i] ? a_base[i] : 0) + k0 + kq * 4, a_ok[i], qm[i]);
+                }
             } else {
                 const int tap = k0 / p.Cin, ci0 = k0 - tap * p.Cin;
                 const int ky = tap / p.kw, kx = tap - ky * p.kw;
@@ -611,18 +630,18 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
                 for (int i = 0; i < PA; ++i) {
                     const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
                     const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-                    qa[i] = ok ? *reinterpret_cast<const f32x4*>(p.A + a_base[i] + ((long)iy * p.Win + ix) * p.lda + ci0 + kq * 4)
-                               : zero4();
+                    const long off = ok ? a_base[i] + ((long)iy * p.Win + ix) * p.lda + ci0 : (long)p.a_coff;
+                    qa[i] = load4_masked(p.A + off + kq * 4, ok, qm[i]);
                 }
             }
         };
-        auto lds_store = [&](int t, const f32x4 (&qa)[PA], const bf16x8 (&qb)[NP][PB]) {
+        auto lds_store = [&](int t, const f32x4 (&qa)[PA], const bf16x8 (&qb)[NP][PB], const float (&qm)[PA]) {
             __bf16* As = smem + (t % NBUF) * BUF;
             __bf16* Bs = As + NP * BM * SLD;
 #pragma unroll
             for (int i = 0; i < PA; ++i) {
                 bf16x4 sp[NP];
-                split4<NP>(qa[i], sp);
+                split4<NP>(qa[i] * qm[i], sp);
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl)
                     *reinterpret_cast<bf16x4*>(As + (pl * BM + lrow + i * RPP) * SLD + kq * 4) = sp[pl];
@@ -635,21 +654,21 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
         };
         constexpr int AHEAD = NBUF - 1;     // LDS tiles the producers run ahead of the consumers
         // prologue: LDS tiles 0 .. AHEAD-1 stored, register sets hold the next two tiles
-        if (nt > 0) gload(0, ra[0], rb[0]);
-        if (nt > 1) gload(1, ra[1], rb[1]);
-        if (nt > 0 && !(p.abl & 2)) lds_store(0, ra[0], rb[0]);
-        if (nt > 2) gload(2, ra[0], rb[0]);
+        if (nt > 0) gload(0, ra[0], rb[0], am[0]);
+        if (nt > 1) gload(1, ra[1], rb[1], am[1]);
+        if (nt > 0 && !(p.abl & 2)) lds_store(0, ra[0], rb[0], am[0]);
+        if (nt > 2) gload(2, ra[0], rb[0], am[0]);
         if (AHEAD > 1) {
-            if (nt > 1 && !(p.abl & 2)) lds_store(1, ra[1], rb[1]);
-            if (nt > 3) gload(3, ra[1], rb[1]);
+            if (nt > 1 && !(p.abl & 2)) lds_store(1, ra[1], rb[1], am[1]);
+            if (nt > 3) gload(3, ra[1], rb[1], am[1]);
         }
         __syncthreads();
         // step t: store tile t+AHEAD (register set (t+AHEAD)&1), refill that set with tile t+AHEAD+2
 #define BRN_PROD_STEP(T, SET)                                                              \
         {                                                                                  \
             if ((T) + AHEAD < nt) {                                                        \
-                if (!(p.abl & 2)) lds_store((T) + AHEAD, ra[SET], rb[SET]);                \
-                if ((T) + AHEAD + 2 < nt && !(p.abl & 1)) gload((T) + AHEAD + 2, ra[SET], rb[SET]); \
+                if (!(p.abl & 2)) lds_store((T) + AHEAD, ra[SET], rb[SET], am[SET]);                \
+                if ((T) + AHEAD + 2 < nt && !(p.abl & 1)) gload((T) + AHEAD + 2, ra[SET], rb[SET], am[SET]); \
             }                                                                              \
             __syncthreads();                                                               \
         }

@@ -10,13 +10,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int LN_MAX_V = 12;   // float4 per lane: C <= 64*4*12 = 3072
 constexpr int LN_WAVES = 4;
 
-template <int MODE>
+template <int MODE, int NV>
 __global__ void __launch_bounds__(LN_WAVES * 64) layernorm_kernel(const LayerNormParams p) {
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
-    if (row >= p.rows) return;
     const int nv = p.C >> 2;   // float4 per row
-    f32x4 v[LN_MAX_V];
+    const long nwaves = (long)gridDim.x * LN_WAVES;
+    // each wave walks rows with a grid stride (few, fat workgroups: the kernel is launch/latency bound otherwise)
+    for (long row = (long)blockIdx.x * LN_WAVES + (threadIdx.x >> 6); row < p.rows; row += nwaves) {
+    f32x4 v[NV];
     int h2 = 0, w2 = 0, bi = 0, Ho = 0, Wo = 0;
     if (MODE == 1) {
         Ho = (p.H + 1) >> 1; Wo = (p.W + 1) >> 1;
@@ -28,7 +29,7 @@ __global__ void __launch_bounds__(LN_WAVES * 64) layernorm_kernel(const LayerNor
     const int cin4 = p.Cin >> 2;
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_V; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c4 = lane + i * 64;
         f32x4 t = {0.f, 0.f, 0.f, 0.f};
         if (c4 < nv) {
@@ -50,7 +51,7 @@ __global__ void __launch_bounds__(LN_WAVES * 64) layernorm_kernel(const LayerNor
     const float mean = sum / (float)p.C;
     float sq = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_V; ++i) {
+    for (int i = 0; i < NV; ++i) {
         if (lane + i * 64 < nv) {
             const f32x4 d = v[i] - mean;
             sq += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
@@ -61,7 +62,7 @@ __global__ void __launch_bounds__(LN_WAVES * 64) layernorm_kernel(const LayerNor
     const float rstd = 1.0f / sqrtf(sq / (float)p.C + p.eps);
     float* yrow = p.y + row * p.ldy + p.y_coff;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_V; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c4 = lane + i * 64;
         if (c4 < nv) {
             const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + c4 * 4);
@@ -69,14 +70,23 @@ __global__ void __launch_bounds__(LN_WAVES * 64) layernorm_kernel(const LayerNor
             *reinterpret_cast<f32x4*>(yrow + c4 * 4) = (v[i] - mean) * rstd * gm + bt;
         }
     }
+    }
 }
 
 hipError_t launch_layernorm(const LayerNormParams& p, hipStream_t s) {
     if (p.C % 4 || p.C > 64 * 4 * LN_MAX_V || p.rows <= 0) return hipErrorInvalidValue;
     if (p.mode == 1 && (p.C != 4 * p.Cin || p.Cin % 4)) return hipErrorInvalidValue;
-    dim3 grid((p.rows + LN_WAVES - 1) / LN_WAVES), block(LN_WAVES * 64);
-    if (p.mode == 0) hipLaunchKernelGGL(layernorm_kernel<0>, grid, block, 0, s, p);
-    else hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, p);
+    long blocks = (p.rows + LN_WAVES - 1) / LN_WAVES;
+    if (blocks > 2048) blocks = 2048;            // 8 workgroups per CU, grid-stride over rows
+    dim3 grid((unsigned)blocks), block(LN_WAVES * 64);
+    const int nvl = (p.C / 4 + 63) / 64;         // float4 per lane
+#define BRN_LN(MODE_, NV_) hipLaunchKernelGGL((layernorm_kernel<MODE_, NV_>), grid, block, 0, s, p)
+#define BRN_LN_NV(MODE_)                                                                        \
+    if (nvl <= 1) BRN_LN(MODE_, 1); else if (nvl <= 2) BRN_LN(MODE_, 2); else if (nvl <= 3) BRN_LN(MODE_, 3); \
+    else if (nvl <= 6) BRN_LN(MODE_, 6); else BRN_LN(MODE_, 12)
+    if (p.mode == 0) { BRN_LN_NV(0); } else { BRN_LN_NV(1); }
+#undef BRN_LN_NV
+#undef BRN_LN
     return hipGetLastError();
 }
 

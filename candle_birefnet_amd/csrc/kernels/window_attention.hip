@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_f32_kernel(const
         const int fw = pw < p.Wp - WS ? 0 : (pw < p.Wp - p.shift ? 1 : 2);
         rid_s[tid] = fh * 3 + fw;
     }
-    for (int i = tid; i < (2 * WS - 1) * (2 * WS - 1); i += ATT_THREADS) tab_s[i] = p.rel_table[i * p.heads + head];
+    for (int i = tid; i < (2 * WS - 1) * (2 * WS - 1); i += ATT_THREADS) tab_s[i] = p.rel_table[head * ((2 * WS - 1) * (2 * WS - 1)) + i];
     __syncthreads();
 
     // ---- stage K and V of this (window, head) into LDS: 144 rows x 8 float4 each ----
