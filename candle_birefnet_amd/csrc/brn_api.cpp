@@ -604,6 +604,30 @@ brn_status brn_deform_conv2d_forward(const float* x, int B, int C, int H, int W,
 // ---- diagnostics -----------------------------------------------------------------------------------------------------
 brn_status brn_gemm_microbench(int M, int N, int K, int tile_cfg, int splitk, int iters, int device, float* ms_per_launch) {
     return guarded([&] {
+        if (tile_cfg == 101 || tile_cfg == 102) {   // bf16 32x32x16 MFMA peak probe (101: 4 accumulators, 102: one dependent chain)
+            ensure_device(device);
+            DeviceOwner own;
+            std::vector<float> z(16, 0.f);
+            float* sink = own.upload(z);
+            unsigned long long* clk = (unsigned long long*)own.upload(z);
+            hipEvent_t e0, e1;
+            BRN_HIP(hipEventCreate(&e0)); BRN_HIP(hipEventCreate(&e1));
+            const int nacc = tile_cfg == 101 ? 4 : 1;
+            BRN_HIP(launch_mfma_peak_bf16(M, N, sink, clk, nacc, nullptr));
+            BRN_HIP(hipEventRecord(e0, nullptr));
+            for (int i = 0; i < iters; ++i) BRN_HIP(launch_mfma_peak_bf16(M, N, sink, clk, nacc, nullptr));
+            BRN_HIP(hipEventRecord(e1, nullptr));
+            BRN_HIP(hipEventSynchronize(e1));
+            float ms = 0.f;
+            BRN_HIP(hipEventElapsedTime(&ms, e0, e1));
+            unsigned long long hc[2];
+            BRN_HIP(hipMemcpy(hc, clk, sizeof hc, hipMemcpyDeviceToHost));
+            const double flop = (double)M * 4 * (double)N * 4 * 32768.0;
+            ms_per_launch[0] = (float)(flop / (ms / iters * 1e-3) / 1e12);
+            if (K > 1) ms_per_launch[1] = hc[1] ? (float)((double)hc[0] / (double)hc[1] * 100.0) : 0.f;
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+            return;
+        }
         if (tile_cfg == 100) {   // MFMA peak probe: M = workgroups, N = MFMA iterations (x4) per wave; returns TF/s, clock via splitk ptr hack-free
             ensure_device(device);
             DeviceOwner own;

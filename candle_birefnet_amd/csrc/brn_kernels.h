@@ -49,6 +49,7 @@ GemmPlan plan_gemm(int M, int N, int K);
 // ws: plan.ws_floats floats of scratch when plan.splitk > 1.  Returns the hipError_t of the launch(es).
 hipError_t launch_gemm(const GemmParams& p, const GemmPlan& plan, float* ws, hipStream_t s);
 
+hipError_t launch_mfma_peak_bf16(int blocks, int iters, float* sink, unsigned long long* clk, int nacc, hipStream_t s);
 hipError_t launch_mfma_peak(int blocks, int iters, float* sink, unsigned long long* clk, hipStream_t s);
 
 struct LayerNormParams {

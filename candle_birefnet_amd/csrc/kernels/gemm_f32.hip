@@ -773,6 +773,37 @@ __global__ void mfma_peak_kernel(int iters, float* sink, unsigned long long* clk
     if (acc == 123.456f) sink[0] = acc;
     if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
 }
+__global__ void mfma_peak_bf16_kernel(int iters, float* sink, unsigned long long* clk, int nacc) {
+    f32x16 a0, a1, a2, a3;
+    for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; a2[r] = 0.f; a3[r] = 0.f; }
+    bf16x8 x, y;
+    for (int j = 0; j < 8; ++j) { x[j] = (__bf16)((float)((threadIdx.x + j) & 7) * 0.125f - 0.4f); y[j] = (__bf16)((float)((threadIdx.x * 3 + j) & 3) * 0.25f - 0.3f); }
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    if (nacc == 4) {
+        for (int i = 0; i < iters; ++i) {
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y, x, a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, x, a2, 0, 0, 0);
+            a3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y, y, a3, 0, 0, 0);
+        }
+    } else {
+        for (int i = 0; i < iters; ++i) {
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a0, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y, x, a0, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, x, a0, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y, y, a0, 0, 0, 0);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float acc = 0.f;
+    for (int r = 0; r < 16; ++r) acc += a0[r] + a1[r] + a2[r] + a3[r];
+    if (acc == 123.456f) sink[0] = acc;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
+}
+hipError_t launch_mfma_peak_bf16(int blocks, int iters, float* sink, unsigned long long* clk, int nacc, hipStream_t s) {
+    hipLaunchKernelGGL(mfma_peak_bf16_kernel, dim3(blocks), dim3(256), 0, s, iters, sink, clk, nacc);
+    return hipGetLastError();
+}
 hipError_t launch_mfma_peak(int blocks, int iters, float* sink, unsigned long long* clk, hipStream_t s) {
     hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, s, iters, sink, clk);
     return hipGetLastError();
