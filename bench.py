@@ -23,6 +23,14 @@ sys.path.insert(0, ROOT)
 GFLOP_PER_IMAGE = {1024: 2534.9, 2048: 9772.6}
 GFLOP_OFFSET_MOD_1024 = 84.0          # offset + modulator convs: computed and discarded on the reference CPU path
 PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md, Peak FP32 (matrix), dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md, Peak BF16 MFMA, dense
+# compute mode -> (bf16 MFMAs per fp32 product or 0 for the fp32 instruction, dtype string)
+MODES = {
+    "f32": (0, "f32 (v_mfma_f32_32x32x2_f32, exact fp32 operands)"),
+    "f32_split3": (6, "f32 storage+accumulate; GEMM operands split error-free into 3 bf16 terms, 6 bf16 MFMAs/product (fp32-equivalent)"),
+    "f32_split2": (3, "f32 storage+accumulate; GEMM operands split into 2 bf16 terms (16-bit mantissa), 3 bf16 MFMAs/product"),
+    "bf16_operands": (1, "bf16 GEMM operands, f32 storage+accumulate"),
+}
 GEMM_FAMILIES = ("gemm_dense", "gemm_conv_nhwc", "gemm_gather_nchw", "gemm_deform_nhwc")
 
 
@@ -34,8 +42,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--deform-mode", default="reference_cpu", choices=["reference_cpu", "deformable"])
-    ap.add_argument("--compute", default="f32", choices=["f32", "f32_split3", "f32_split2", "bf16_operands"],
+    ap.add_argument("--compute", default="f32_split2", choices=list(MODES),
                     help="arithmetic of the contraction kernels (include/birefnet_hip.h brn_dtype)")
+    ap.add_argument("--also", default="f32", help="comma list of other compute modes to time briefly on rank 0 at N=1 ('' = none)")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra steps with per-launch HIP events for the roofline block")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off", "on"])
     ap.add_argument("--cpu-baseline-size", type=int, default=0, help="image side for the CPU oracle sample (0 = choose)")
@@ -107,10 +116,16 @@ def main():
         model.set_profiling(False)
         n = args.profile_steps
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        npairs = MODES[args.compute][0]
+        peak = PEAK_F32_MFMA_TFLOPS if npairs == 0 else PEAK_BF16_MFMA_TFLOPS / npairs
         roof = {
-            "bound": "mfma", "kernel": "gemm_f32_kernel (dense / conv_nhwc / gather_nchw / deform_nhwc)",
-            "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "bound": "mfma",
+            "kernel": "gemm family: gemm_f32_kernel" if npairs == 0 else "gemm family: gemm_split_ws_kernel / gemm_split_kernel (+ gemm_f32_kernel for the NCHW-gather convs)",
+            "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": None,
+            "peak_note": ("fp32 MFMA dense peak" if npairs == 0 else
+                          f"bf16 MFMA dense peak 2500 / {npairs} MFMAs per fp32 product; achieved counts ALGORITHMIC 2*M*N*K "
+                          f"(= {achieved / PEAK_F32_MFMA_TFLOPS:.2f}x the fp32-MFMA peak of {PEAK_F32_MFMA_TFLOPS})"),
             "launches_per_step": launches // n, "gflop_per_step": round(fl / n / 1e9, 1), "ms_per_step": round(ms / n, 3),
             "avg_launch_ms": round(ms / max(1, launches), 4),
             "algorithmic_gbytes_per_step": round(by / n / 1e9, 2),
@@ -138,6 +153,26 @@ def main():
             cpu["gpu_vs_oracle_max_abs_err"] = float(err.max())
             cpu["gpu_vs_oracle_gate_1e-3abs_or_1e-2rel"] = bool(((err <= 1e-3) | (err <= 1e-2 * np.abs(ref))).all())
 
+    # ---- the other compute modes, briefly (rank 0, N=1): same weights, same input, 5 timed steps each ----
+    others = None
+    if rank == 0 and world == 1 and args.also:
+        others = {}
+        ref_np = ref if (cpu is not None and (args.cpu_baseline_size or S) == S) else None
+        for mode in [m for m in args.also.split(",") if m and m != args.compute]:
+            m2 = cb.BiRefNet.new(cfg, cb.VarBuilder.from_tensors(weights), device=local_rank, max_batch=B, max_size=(S, S), compute=mode)
+            for _ in range(2):
+                y2 = m2.forward_logits(x)
+            torch.cuda.synchronize()
+            t0m = time.perf_counter()
+            for _ in range(5):
+                y2 = m2.forward_logits(x)
+            torch.cuda.synchronize()
+            dtm = (time.perf_counter() - t0m) / 5
+            others[mode] = {"images_per_s": round(B / dtm, 3), "ms_per_step": round(dtm * 1e3, 3), "dtype": MODES[mode][1]}
+            if ref_np is not None:
+                others[mode]["gpu_vs_oracle_max_abs_err"] = float(np.abs(y2[:1].cpu().numpy().astype(np.float64) - ref_np).max())
+            m2.close()
+
     if rank == 0:
         images = args.steps * B * world
         value = images / elapsed
@@ -146,19 +181,20 @@ def main():
             "metric": "images/sec @1024x1024 Swin-L" if S == 1024 else f"images/sec @{S}x{S} Swin-L",
             "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": MODES[args.compute][1], "data": "synthetic",
             "config": {"workload": f"BiRefNetConfig::swin_l() forward_logits, batch {B}/GPU, {S}x{S}, fp32 (BASELINE configs[1] shape)",
                        "batch_per_gpu": B, "global_batch": B * world, "size": S, "deform_mode": args.deform_mode,
+                       "compute": args.compute,
                        "parallelism": f"{world} replica(s), batch-sharded, no data-path collective",
                        "inputs": "resident in HBM (torch cuda tensors), weights: synthetic seed 42"},
             "outputs_finite": finite,
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "other_modes": others,
         }
         if gflop_ref:
             g = gflop_ref - (GFLOP_OFFSET_MOD_1024 * (S / 1024) ** 2 if args.deform_mode == "reference_cpu" else 0.0)
             out["path"] = {"reference_gflop_per_image": round(g, 1),
                            "tflops_at_reference_count": round(value / world * g / 1e3, 2),
-                           "frac_of_f32_mfma_peak": round(value / world * g / 1e3 / PEAK_F32_MFMA_TFLOPS, 4)}
+                           "x_of_f32_mfma_peak": round(value / world * g / 1e3 / PEAK_F32_MFMA_TFLOPS, 4)}
         if stage_ms:
             out["stage_ms_profiled"] = {k: round(v, 3) for k, v in stage_ms.items()}
         print(json.dumps(out), flush=True)

@@ -415,12 +415,25 @@ brn_status brn_swin_forward(brn_swin* s, const float* x, int B, int H, int W, br
 }
 
 // ---- op-level entry points (weights are always host pointers; x / y / residual follow `loc`) -------------------------------------
+static thread_local int g_op_planes = 0;
+brn_status brn_set_op_compute(int dtype) {
+    return guarded([&] {
+        if (dtype == BRN_F32) g_op_planes = 0;
+        else if (dtype == BRN_F32_SPLIT3) g_op_planes = 3;
+        else if (dtype == BRN_F32_SPLIT2) g_op_planes = 2;
+        else if (dtype == BRN_BF16_OPERANDS) g_op_planes = 1;
+        else fail(BRN_ERR_INVALID_ARG, "unsupported compute dtype %d", dtype);
+    });
+}
+struct OpPlanes { OpPlanes() { set_build_planes(g_op_planes); } ~OpPlanes() { set_build_planes(0); } };
+
 brn_status brn_linear_forward(const float* x, int M, int K, const float* w, const float* bias, int N, int act,
                               const float* residual, float* y, brn_mem loc, int device, void* stream) {
     return guarded([&] {
         if (!x || !w || !y || M < 1 || N < 1 || K < 1) fail(BRN_ERR_INVALID_ARG, "bad argument");
         ensure_device(device);
         DeviceOwner own;
+        OpPlanes op_planes;
         GemmW g = make_linear(own, w, bias, N, K);
         g.act = act;
         Staging st(stream, loc);
@@ -461,6 +474,7 @@ brn_status brn_conv2d_forward(const float* x, int B, int C, int H, int W, const 
         if (Ho < 1 || Wo < 1) fail(BRN_ERR_INVALID_ARG, "empty conv output");
         ensure_device(device);
         DeviceOwner own;
+        OpPlanes op_planes;
         const bool nhwc = (C % 32) == 0;
         GemmW g = nhwc ? make_conv_nhwc(own, w, nullptr, O, C, C, kh, kw, stride, pad, dil)
                        : make_conv_gather(own, w, nullptr, O, C, kh, kw, stride, pad, dil);

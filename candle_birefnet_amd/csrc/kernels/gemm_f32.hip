@@ -551,12 +551,14 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_split_kernel(const GemmParam
 // registers: at bf16 MFMA rates an exposed LDS read (~250 cycles) per 32-deep K tile (768 MFMA cycles) was a third of the
 // loop (measured by ablation: staging and MFMA phases added up, then the fragment-read stall did).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int MODE, int NP>
+template <int MODE, int NP, int KS>   // KS = k elements per LDS stage (32, or 16 to halve the stage when 3 planes must fit twice per CU)
 __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) {
     constexpr int BM = 128, BN = 128, WTM = 64, WTN = 64, TM = 2, TN = 2;
+    constexpr int SLD = KS + 8;                     // bf16 per LDS row (16-byte pad: conflict-free b128 fragment reads)
+    constexpr int KSTEPS = KS / 16;                 // MFMA k-steps per stage
     constexpr int NBUF = 2;                         // 2 x NP x 20 KB: two workgroups per CU at NP <= 2 (a 3-deep ring was slower: 1 WG/CU exposes each tile's prologue + epilogue)
-    constexpr int RPP = 32, PA = BM / RPP;          // producers: 256 threads, 8 float4 per 32-float row
-    constexpr int WRPP = 64, PB = BN / WRPP;        // 4 x 16-byte chunks per 32-bf16 row
+    constexpr int AQ = KS / 4, RPP = 256 / AQ, PA = BM / RPP;   // producers: 256 threads, AQ float4 per KS-float row
+    constexpr int WQ = KS / 8, WRPP = 256 / WQ, PB = BN / WRPP; // WQ 16-byte chunks per KS-bf16 row
     constexpr int BUF = NP * (BM + BN) * SLD;       // bf16 elements per LDS buffer
     constexpr int SMEM_MAIN = NBUF * BUF * 2, SMEM_EPI = 4 * EPI_WAVE_FLOATS * 4;   // bytes
     __shared__ __attribute__((aligned(16))) char smem_raw[SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI];
@@ -576,14 +578,14 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
     int tile_m, tile_n;
     tile_coords(tile, (p.M + BM - 1) / BM, tilesN, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int nk_all = p.K / BK;
+    const int nk_all = p.K / KS;
     const int kts = (nk_all + p.splitk - 1) / p.splitk;
     const int kt0 = slice * kts, nk = min(nk_all, kt0 + kts);
     const int nt = nk > kt0 ? nk - kt0 : 0;         // K tiles of this slice; local tile index t = kt - kt0
 
     if (producer) {
         const int pt = tid - 256;
-        const int kq = pt & 7, lrow = pt >> 3;
+        const int kq = pt % AQ, lrow = pt / AQ;
         long a_base[PA];
         int a_iy[PA], a_ix[PA];
         bool a_ok[PA];
@@ -603,14 +605,14 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
                 a_base[i] = (long)b * p.Hin * p.Win * p.lda + p.a_coff;
             }
         }
-        const int wc = pt & 3, wrow = pt >> 2;
+        const int wc = pt % WQ, wrow = pt / WQ;
         const long wplane = (long)p.wp_rows * p.K;
         const __bf16* wsrc = reinterpret_cast<const __bf16*>(p.Wp) + (long)(n0 + wrow) * p.K + wc * 8;
         f32x4 ra[2][PA];
         bf16x8 rb[2][NP][PB];
         float am[2][PA];
         auto gload = [&](int t, f32x4 (&qa)[PA], bf16x8 (&qb)[NP][PB], float (&qm)[PA]) {
-            const int k0 = (kt0 + t) * BK;
+            const int k0 = (kt0 + t) * KS;
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
@@ -722,13 +724,17 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
     if (nt > 0 && !(p.abl & 4)) read_frags(0, 0, fa0, fb0);
     for (int t = 0; t < nt; ++t) {
         if (!(p.abl & 4)) {
-            read_frags(t, 1, fa1, fb1);
-            mfma_all(fa0, fb0);
-            if (XPREFETCH && t + 1 < nt) read_frags(t + 1, 0, fa0, fb0);
-            mfma_all(fa1, fb1);
+            if (KSTEPS == 2) {
+                read_frags(t, 1, fa1, fb1);
+                mfma_all(fa0, fb0);
+                if (XPREFETCH && t + 1 < nt) read_frags(t + 1, 0, fa0, fb0);
+                mfma_all(fa1, fb1);
+            } else {
+                mfma_all(fa0, fb0);
+            }
         }
         __syncthreads();
-        if (!XPREFETCH && t + 1 < nt && !(p.abl & 4)) read_frags(t + 1, 0, fa0, fb0);
+        if ((!XPREFETCH || KSTEPS == 1) && t + 1 < nt && !(p.abl & 4)) read_frags(t + 1, 0, fa0, fb0);
     }
     // producers have left; the staging LDS is free for the epilogue patches (all LDS reads retired by the last barrier)
     gemm_epilogue<TM, TN, WTM, WTN>(p, acc, m0, n0, wm, wn, lane, slice, reinterpret_cast<float*>(smem_raw) + wave * EPI_WAVE_FLOATS);
@@ -738,8 +744,9 @@ template <int NP>
 static hipError_t launch_split_ws(const GemmParams& p, hipStream_t s) {
     const int tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128) * p.splitk;
     dim3 grid(tiles), block(512);
-    if (p.mode == GEMM_DENSE) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, NP>), grid, block, 0, s, p);
-    else if (p.mode == GEMM_CONV_NHWC) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_CONV_NHWC, NP>), grid, block, 0, s, p);
+    constexpr int KS = 32;                  // (16-deep stages were tried for 3 planes: registers, not LDS, cap residency; slower)
+    if (p.mode == GEMM_DENSE) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, NP, KS>), grid, block, 0, s, p);
+    else if (p.mode == GEMM_CONV_NHWC) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_CONV_NHWC, NP, KS>), grid, block, 0, s, p);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -3,6 +3,14 @@ Weights are host arrays; activations may be numpy (host) or torch-on-GPU (device
 from . import _ffi
 from . import tensors as T
 
+_COMPUTE = {"f32": _ffi.BRN_F32, "f32_split3": _ffi.BRN_F32_SPLIT3, "f32_split2": _ffi.BRN_F32_SPLIT2, "bf16_operands": _ffi.BRN_BF16_OPERANDS}
+
+
+def set_compute(mode: str):
+    """contraction arithmetic of ops.linear / ops.conv2d on this thread (include/birefnet_hip.h brn_dtype)"""
+    _ffi.check(_ffi.lib.brn_set_op_compute(_COMPUTE[mode]))
+
+
 _ACT = {None: _ffi.BRN_ACT_NONE, "none": _ffi.BRN_ACT_NONE, "relu": _ffi.BRN_ACT_RELU, "gelu_erf": _ffi.BRN_ACT_GELU_ERF}
 
 

@@ -157,6 +157,9 @@ brn_status brn_swin_forward(brn_swin* s, const float* x_nchw, int B, int H, int 
                             float* const outs[4], brn_mem out_loc, void* stream);
 
 /* ---- op-level entry points (the candle ops the reference calls; used by the parity tests) -------------- */
+/* Selects the contraction arithmetic (brn_dtype) used by brn_linear_forward / brn_conv2d_forward on the calling thread
+ * (default BRN_F32); models carry their own setting from brn_model_create. */
+brn_status brn_set_op_compute(int dtype);
 /* candle_nn::linear / linear_no_bias + optional gelu_erf + optional residual (swin.rs:98-107,130-131,406-407):
  * y[M,N] = act(x[M,K] @ w[N,K]^T + bias) (+ residual[M,N]).  bias/residual may be NULL. */
 brn_status brn_linear_forward(const float* x, int M, int K, const float* w, const float* bias, int N,
