@@ -251,12 +251,15 @@ static Tensor cat_channels(const std::vector<const Tensor*>& ts) {
     const int64_t B = ts[0]->dim(0), H = ts[0]->dim(2), W = ts[0]->dim(3);
     int64_t Ct = 0; for (auto t : ts) Ct += t->dim(1);
     Tensor y({B, Ct, H, W});
+    for (auto t : ts)
+        if (t->dim(0) != B || t->dim(2) != H || t->dim(3) != W) die("cat: shape mismatch");
     for (int64_t b = 0; b < B; ++b) {
         int64_t c0 = 0;
         for (auto t : ts) {
-            if (t->dim(0) != B || t->dim(2) != H || t->dim(3) != W) die("cat: shape mismatch");
             const int64_t C = t->dim(1);
-            memcpy(y.p() + (b * Ct + c0) * H * W, t->p() + b * C * H * W, (size_t)C * H * W * sizeof(float));
+#pragma omp parallel for
+            for (int64_t c = 0; c < C; ++c)
+                memcpy(y.p() + (b * Ct + c0 + c) * H * W, t->p() + (b * C + c) * H * W, (size_t)H * W * sizeof(float));
             c0 += C;
         }
     }
@@ -403,6 +406,7 @@ static Tensor attention_half(const Tensor& xn, const Weights& w, const std::stri
     const int64_t B = xn.dim(0), H = xn.dim(1), W = xn.dim(2), C = xn.dim(3);
     const int64_t pad_r = (ws - W % ws) % ws, pad_b = (ws - H % ws) % ws, hp = H + pad_b, wp = W + pad_r;
     Tensor x({B, hp, wp, C});                                       // pad_with_zeros (swin.rs:359-366)
+#pragma omp parallel for collapse(2)
     for (int64_t b = 0; b < B; ++b) for (int64_t i = 0; i < H; ++i)
         memcpy(x.p() + ((b * hp + i) * wp) * C, xn.p() + ((b * H + i) * W) * C, (size_t)W * C * sizeof(float));
     if (shift > 0) x = roll_2d(x, -shift, -shift);                  // swin.rs:371-377
@@ -413,6 +417,7 @@ static Tensor attention_half(const Tensor& xn, const Weights& w, const std::stri
     Tensor sx = window_reverse(aw, ws, hp, wp);                     // swin.rs:387
     if (shift > 0) sx = roll_2d(sx, shift, shift);                  // swin.rs:390-394
     Tensor y({B, H, W, C});                                         // narrow (swin.rs:397-401)
+#pragma omp parallel for collapse(2)
     for (int64_t b = 0; b < B; ++b) for (int64_t i = 0; i < H; ++i)
         memcpy(y.p() + ((b * H + i) * W) * C, sx.p() + ((b * hp + i) * wp) * C, (size_t)W * C * sizeof(float));
     return y;
@@ -446,6 +451,7 @@ static Tensor patch_merging(const Tensor& x, int64_t H, int64_t W, const Weights
     const int64_t H2 = (H + 1) / 2, W2 = (W + 1) / 2;
     Tensor c4({B, H2 * W2, 4 * C});
     auto at = [&](int64_t b, int64_t i, int64_t j) -> const float* { return (i < H && j < W) ? x.p() + ((b * H + i) * W + j) * C : nullptr; };
+#pragma omp parallel for collapse(2)
     for (int64_t b = 0; b < B; ++b) for (int64_t i = 0; i < H2; ++i) for (int64_t j = 0; j < W2; ++j) {
         float* dst = c4.p() + ((b * H2 + i) * W2 + j) * 4 * C;
         const float* src[4] = {at(b, 2 * i, 2 * j), at(b, 2 * i + 1, 2 * j), at(b, 2 * i, 2 * j + 1), at(b, 2 * i + 1, 2 * j + 1)};   // x0,x1,x2,x3 swin.rs:509-516
@@ -474,7 +480,8 @@ static std::vector<Tensor> swin_forward(const Tensor& x_in, const Weights& w, co
     Tensor pe = conv2d(x, w.get(p + "patch_embed.proj.weight", {E, (int64_t)cfg.in_ch, P, P}), w.get(p + "patch_embed.proj.bias", {E}), E, P, P, P, 0, 1);
     int64_t h = pe.dim(2), wd = pe.dim(3);
     Tensor tok({B, h * wd, E});                                     // flatten(2).transpose(1,2) (swin.rs:708, 774)
-    for (int64_t b = 0; b < B; ++b) for (int64_t c = 0; c < E; ++c) for (int64_t i = 0; i < h * wd; ++i)
+#pragma omp parallel for collapse(2)
+    for (int64_t b = 0; b < B; ++b) for (int64_t i = 0; i < h * wd; ++i) for (int64_t c = 0; c < E; ++c)
         tok.d[(b * h * wd + i) * E + c] = pe.d[(b * E + c) * h * wd + i];
     tok = layer_norm(tok, w.get(p + "patch_embed.norm.weight", {E}), w.get(p + "patch_embed.norm.bias", {E}), 1e-5f);
     std::vector<Tensor> outs;
@@ -488,7 +495,8 @@ static std::vector<Tensor> swin_forward(const Tensor& x_in, const Weights& w, co
             tok = swin_block(tok, h, wd, w, lp + "blocks." + std::to_string(j) + ".", cfg.heads[i], ws, (j % 2 == 0) ? 0 : shift, &mask);
         Tensor n = layer_norm(tok, w.get(p + "norm" + std::to_string(i) + ".weight", {C}), w.get(p + "norm" + std::to_string(i) + ".bias", {C}), 1e-5f);
         Tensor o({B, C, h, wd});                                    // reshape(B,h,w,C).permute(0,3,1,2) (swin.rs:786-788)
-        for (int64_t b = 0; b < B; ++b) for (int64_t t = 0; t < h * wd; ++t) for (int64_t c = 0; c < C; ++c)
+#pragma omp parallel for collapse(2)
+        for (int64_t b = 0; b < B; ++b) for (int64_t c = 0; c < C; ++c) for (int64_t t = 0; t < h * wd; ++t)
             o.d[(b * C + c) * h * wd + t] = n.d[(b * h * wd + t) * C + c];
         outs.push_back(std::move(o));
         if (i < 3) {
@@ -546,6 +554,7 @@ static Tensor deform_conv2d(const Tensor& x, const Tensor& offset, const Tensor&
             }
         }
         sgemm_nt(P, O, CK, col.data(), CK, W, CK, out.data(), O);
+#pragma omp parallel for
         for (int64_t o = 0; o < O; ++o) for (int64_t pp = 0; pp < P; ++pp) y.d[(b * O + o) * P + pp] = out[(size_t)pp * O + o] + (bias ? bias[o] : 0.f);
     }
     return y;
@@ -575,6 +584,7 @@ static Tensor aspp_deformable(const Tensor& x, const Weights& w, const std::stri
     Tensor x1 = module(p + "aspp1.", 1);
     Tensor d0 = module(p + "aspp_deforms.0.", 1), d1 = module(p + "aspp_deforms.1.", 3), d2 = module(p + "aspp_deforms.2.", 7);
     Tensor g({B, C, 1, 1});                                           // mean_keepdim(H) then mean_keepdim(W) (aspp.rs:314)
+#pragma omp parallel for
     for (int64_t bc = 0; bc < B * C; ++bc) {
         std::vector<float> colmean((size_t)W, 0.f);
         for (int64_t j = 0; j < W; ++j) { float s = 0.f; for (int64_t i = 0; i < H; ++i) s += x.d[(bc * H + i) * W + j]; colmean[j] = s / (float)H; }
@@ -584,6 +594,7 @@ static Tensor aspp_deformable(const Tensor& x, const Weights& w, const std::stri
     Tensor x5 = conv_named(g, w, p + "global_avg_pool.1", 256, 1, 0, false);
     bn_named_(x5, w, p + "global_avg_pool.2"); relu_(x5);
     Tensor x5u({B, 256, H, W});                                       // upsample_nearest2d (aspp.rs:318)
+#pragma omp parallel for
     for (int64_t bc = 0; bc < B * 256; ++bc) std::fill(x5u.p() + bc * H * W, x5u.p() + (bc + 1) * H * W, x5.d[bc]);
     Tensor cat = cat_channels({&x1, &d0, &d1, &d2, &x5u});            // aspp.rs:321-327
     Tensor out = conv_named(cat, w, p + "conv1", C, 1, 0, false);     // out_channels = in_channels (aspp.rs:242)
@@ -609,6 +620,7 @@ static Tensor simple_convs(const Tensor& x, const Weights& w, const std::string&
 static Tensor image2patches(const Tensor& x, int64_t th, int64_t tw) {
     const int64_t B = x.dim(0), C = x.dim(1), H = x.dim(2), W = x.dim(3), gh = H / th, gw = W / tw;
     Tensor y({B, C * gh * gw, th, tw});
+#pragma omp parallel for collapse(2)
     for (int64_t b = 0; b < B; ++b) for (int64_t c = 0; c < C; ++c) for (int64_t a = 0; a < gh; ++a) for (int64_t e = 0; e < gw; ++e)
         for (int64_t i = 0; i < th; ++i)
             memcpy(y.p() + (((b * C * gh * gw) + (c * gh + a) * gw + e) * th + i) * tw, x.p() + ((b * C + c) * H + a * th + i) * W + e * tw, (size_t)tw * sizeof(float));
@@ -616,6 +628,7 @@ static Tensor image2patches(const Tensor& x, int64_t th, int64_t tw) {
 }
 static void broadcast_mul_(Tensor& p, const Tensor& a) {   // p [B,C,H,W] * a [B,1,H,W] (birefnet.rs:329)
     const int64_t B = p.dim(0), C = p.dim(1), P = p.dim(2) * p.dim(3);
+#pragma omp parallel for collapse(2)
     for (int64_t b = 0; b < B; ++b) for (int64_t c = 0; c < C; ++c) for (int64_t i = 0; i < P; ++i) p.d[(b * C + c) * P + i] *= a.d[b * P + i];
 }
 

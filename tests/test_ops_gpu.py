@@ -167,3 +167,32 @@ def test_deform_conv2d(gpu, k, stride, pad, O, H, mode):
         msk = 1.0 / (torch.exp(-F.conv2d(xt, td["modulator_conv.weight"], td["modulator_conv.bias"], stride=stride, padding=pad)) + 1.0) * 2.0
         ref = R.deform_conv2d(xt, off, msk, td["regular_conv.weight"], td["regular_conv.bias"], stride, pad)
     _close(y, ref.numpy(), tol=1e-4 if mode == "deformable" else 3e-5)
+
+
+@pytest.mark.parametrize("mode,tol", [("f32_split3", 3e-5), ("f32_split2", 1e-4), ("bf16_operands", 3e-2)])
+@pytest.mark.parametrize("M,K,N", [(300, 192, 576), (129, 768, 200), (5000, 384, 1536), (7, 96, 130), (1024, 3072, 768), (64, 51840, 64)])
+def test_linear_split_modes(gpu, mode, tol, M, K, N):
+    """the split-bf16 contraction kernels (all tile configs incl. the warp-specialised one and split-K) against fp64"""
+    from candle_birefnet_amd import ops
+    x, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, std=K ** -0.5), rnd(N, seed=3), rnd(M, N, seed=4)
+    ops.set_compute(mode)
+    try:
+        y = ops.linear(x, w, b, act="gelu_erf", residual=r)
+    finally:
+        ops.set_compute("f32")
+    ref = F.gelu(torch.from_numpy(x).double() @ torch.from_numpy(w).double().T + torch.from_numpy(b).double()) + torch.from_numpy(r).double()
+    _close(y, ref.numpy(), tol=tol)
+
+
+@pytest.mark.parametrize("mode,tol", [("f32_split3", 3e-5), ("f32_split2", 1e-4)])
+@pytest.mark.parametrize("B,C,H,W,O,k,p", [(2, 64, 16, 16, 256, 3, 1), (1, 64, 20, 12, 256, 7, 3), (1, 96, 33, 31, 64, 3, 1), (1, 480, 64, 64, 64, 3, 1)])
+def test_conv2d_split_modes(gpu, mode, tol, B, C, H, W, O, k, p):
+    from candle_birefnet_amd import ops
+    x, w, b = rnd(B, C, H, W, seed=1), rnd(O, C, k, k, seed=2, std=(C * k * k) ** -0.5), rnd(O, seed=3)
+    ops.set_compute(mode)
+    try:
+        y = ops.conv2d(x, w, b, padding=p)
+    finally:
+        ops.set_compute("f32")
+    ref = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=p)
+    _close(y, ref.numpy(), tol=tol)
