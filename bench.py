@@ -118,11 +118,21 @@ def main():
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         npairs = MODES[args.compute][0]
         peak = PEAK_F32_MFMA_TFLOPS if npairs == 0 else PEAK_BF16_MFMA_TFLOPS / npairs
+        # HBM-side bytes per launch of the gemm family: PMC counters cannot be read from inside this process; the figure is
+        # the committed rocprofv3 measurement of this very command (profiles/README.md), only quoted when the config matches
+        traffic, traffic_note = None, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE not collected for this configuration"
+        tj = os.path.join(ROOT, "profiles", "r01_final_gemm_traffic.json")
+        if os.path.exists(tj) and (B, S, args.compute, args.deform_mode) == (1, 1024, "f32_split2", "reference_cpu"):
+            t = json.load(open(tj))
+            traffic = round((t["hbm_read_gb_x2corrected"] + t["hbm_write_gb"]) * 1e9 / t["gemm_family_dispatches"])
+            traffic_note = ("bytes per launch, gemm family average, from profiles/r01_final_pmc_hbm_b1_1024_split2.csv (FETCH_SIZE x2 "
+                            "gfx950 correction + WRITE_SIZE, separate passes); algorithmic bytes per launch = "
+                            f"{round(by / n / max(1, launches // n))}")
         roof = {
             "bound": "mfma",
             "kernel": "gemm family: gemm_f32_kernel" if npairs == 0 else "gemm family: gemm_split_ws_kernel / gemm_split_kernel (+ gemm_f32_kernel for the NCHW-gather convs)",
             "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": None,
+            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
             "peak_note": ("fp32 MFMA dense peak" if npairs == 0 else
                           f"bf16 MFMA dense peak 2500 / {npairs} MFMAs per fp32 product; achieved counts ALGORITHMIC 2*M*N*K "
                           f"(= {achieved / PEAK_F32_MFMA_TFLOPS:.2f}x the fp32-MFMA peak of {PEAK_F32_MFMA_TFLOPS})"),
