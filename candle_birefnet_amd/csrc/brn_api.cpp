@@ -527,6 +527,7 @@ brn_status brn_window_attention_forward(const float* x, int B, int H, int W, int
         int64_t s_qw[2] = {3 * C, C}, s_qb[1] = {3 * C}, s_pw[2] = {C, C}, s_pb[1] = {C}, s_t[2] = {T, heads};
         SwinBlockW bk;
         bk.heads = heads;
+        OpPlanes op_planes;
         bk.qkv = make_linear(own, qkv_w, qkv_b, 3 * C, C);
         bk.proj = make_linear(own, proj_w, proj_b, C, C);
         (void)s_qw; (void)s_qb; (void)s_pw; (void)s_pb; (void)s_t;

@@ -175,6 +175,7 @@ static void swin_attention_multi(Ctx& c, const SwinBlockW& blk, const float* xn,
             p.B = B; p.H = hs[k]; p.W = wsz[k]; p.C = C; p.heads = blk.heads;
             p.Hp = roundup(hs[k], 12); p.Wp = roundup(wsz[k], 12);   // swin.rs:359-360
             p.shift = shift; p.scale = 1.0f / sqrtf(32.0f);          // head_dim^-0.5 (swin.rs:134)
+            p.planes = (blk.qkv.planes == 2 || blk.qkv.planes == 1) ? blk.qkv.planes : 0;
             const double nwin = (double)B * (p.Hp / 12) * (p.Wp / 12) * blk.heads;
             Bracket b(c, FAM_ATTENTION, nwin * 2.0 * 2.0 * 144 * 144 * 32, 4.0 * ((double)Mk * 4 * C), Mk, C, shift);
             BRN_LAUNCH(launch_window_attention(p, c.stream));

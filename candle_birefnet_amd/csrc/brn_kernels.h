@@ -73,6 +73,7 @@ struct WindowAttnParams {
     int Hp, Wp;           // padded canvas (multiples of 12)
     int shift;            // 0 or 6
     float scale;          // head_dim^-0.5
+    int planes;           // 0: fp32 MFMA kernel (modes f32, f32_split3); 2 / 1: bf16-split kernel (f32_split2 / bf16_operands)
 };
 hipError_t launch_window_attention(const WindowAttnParams& p, hipStream_t s);
 

@@ -154,12 +154,223 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_f32_kernel(const
     }
 }
 
+// =====================================================================================================================
+// window_attention_split_kernel — the same fused window attention on the bf16 matrix cores (compute modes f32_split2 /
+// bf16_operands).  q*scale, K, V and the softmax numerators P are split into NP bf16 terms (x ~ x_h + x_l) in registers /
+// while staging, every product is the sum of the NP*(NP+1)/2 leading plane products on v_mfma_f32_16x16x32_bf16 (head_dim
+// 32 = ONE MFMA k), accumulation, bias, mask and softmax stay fp32.  MFMA cycles per 16-query tile: 57 x 16 vs 144 x 32.
+// LDS (40.2 KB -> 4 workgroups per CU instead of 3: the 864 workgroups of a Swin-L stage-2 launch fit one round):
+//   Kp[pl][key][32 d]   bf16, 64-byte rows, 16-byte chunk c stored at c ^ perm[(key >> 2) & 3], perm = {0,2,3,1}
+//                       (conflict-free ds_read_b128 of the A operand: row = key, k = d = 8g + j)
+//   Vt[pl][d][148 keys] bf16 (V transposed): the A operand of O^T = V^T P^T needs 8 keys per lane for a fixed d; the k slots
+//                       of an MFMA over key tiles (2t, 2t+1) are ordered so that lane group g contracts keys 16*(2t)+4g+0..3
+//                       and 16*(2t+1)+4g+0..3 — exactly the keys whose P^T values the lane already holds in its S^T
+//                       accumulators (C/D map row = 4g + reg) — so P never leaves registers.
+// =====================================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+constexpr int VT_LD = 148;
+
+__device__ __forceinline__ int kswz(int key) { return (0x78 >> (2 * ((key >> 2) & 3))) & 3; }
+
+template <int NP>
+__global__ void __launch_bounds__(ATT_THREADS) window_attention_split_kernel(const WindowAttnParams p) {
+    __shared__ __attribute__((aligned(16))) __bf16 Kp[NP * NTOK * HD];
+    __shared__ __attribute__((aligned(16))) __bf16 Vt[NP * HD * VT_LD];
+    __shared__ float tab_s[(2 * WS - 1) * (2 * WS - 1)];
+    __shared__ int src_s[NTOK];
+    __shared__ unsigned char rid_s[NTOK];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int head = blockIdx.y;
+    const int nWw = p.Wp / WS, nW = (p.Hp / WS) * nWw;
+    const int bw = blockIdx.x;
+    const int b = bw / nW, w = bw - b * nW;
+    const int wr = w / nWw, wc = w - wr * nWw;
+    const int C = p.C, C3 = 3 * C;
+
+    if (tid < NTOK) {
+        const int ti = tid / WS, tj = tid - ti * WS;
+        const int ph = wr * WS + ti, pw = wc * WS + tj;
+        int sh = ph + p.shift, sw = pw + p.shift;
+        if (sh >= p.Hp) sh -= p.Hp;
+        if (sw >= p.Wp) sw -= p.Wp;
+        src_s[tid] = (sh < p.H && sw < p.W) ? (b * p.H + sh) * p.W + sw : -1;
+        const int fh = ph < p.Hp - WS ? 0 : (ph < p.Hp - p.shift ? 1 : 2);
+        const int fw = pw < p.Wp - WS ? 0 : (pw < p.Wp - p.shift ? 1 : 2);
+        rid_s[tid] = (unsigned char)(fh * 3 + fw);
+    }
+    for (int i = tid; i < (2 * WS - 1) * (2 * WS - 1); i += ATT_THREADS) tab_s[i] = p.rel_table[head * ((2 * WS - 1) * (2 * WS - 1)) + i];
+    __syncthreads();
+
+    // ---- stage K (row-major, swizzled) and V (transposed), split into bf16 planes: items = (token pair, 4-wide d chunk) ----
+    for (int idx = tid; idx < (NTOK / 2) * 8; idx += ATT_THREADS) {
+        const int tp = idx >> 3, c4 = (idx & 7) * 4;
+        f32x4 kv[2], vv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = tp * 2 + u, src = src_s[t];
+            const float* kp = src >= 0 ? p.qkv + (long)src * C3 + C + head * HD + c4 : p.qkv_bias + C + head * HD + c4;
+            kv[u] = *reinterpret_cast<const f32x4*>(kp);
+            vv[u] = *reinterpret_cast<const f32x4*>(kp + C);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = tp * 2 + u;
+            f32x4 r = kv[u];
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+                bf16x4 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = (__bf16)r[e];
+                *reinterpret_cast<bf16x4*>(Kp + (pl * NTOK + t) * HD + (((c4 >> 3) ^ kswz(t)) << 3) + (c4 & 4)) = h;
+                if (pl + 1 < NP) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r[e] -= (float)h[e];
+                }
+            }
+        }
+        f32x4 r0 = vv[0], r1 = vv[1];
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bf16x2 h;
+                h[0] = (__bf16)r0[e]; h[1] = (__bf16)r1[e];
+                *reinterpret_cast<bf16x2*>(Vt + (pl * HD + c4 + e) * VT_LD + tp * 2) = h;   // keys (2tp, 2tp+1) of row d = c4+e
+                if (pl + 1 < NP) { r0[e] -= (float)h[0]; r1[e] -= (float)h[1]; }
+            }
+        }
+    }
+    __syncthreads();
+
+    const int li = lane & 15, g = lane >> 4;
+    for (int qt = wave; qt < 9; qt += 3) {
+        const int qtok = qt * 16 + li;
+        const int qsrc = src_s[qtok];
+        const int qrid = rid_s[qtok];
+        const int qbase = (qtok / WS + WS - 1) * (2 * WS - 1) + (qtok % WS) + WS - 1;
+        // Q fragment (B operand of S^T = K Q^T): d = 8g .. 8g+7 of this lane's query, scaled (swin.rs:278), split
+        bf16x8 qf[NP];
+        {
+            const float* qp = qsrc >= 0 ? p.qkv + (long)qsrc * C3 + head * HD + g * 8 : p.qkv_bias + head * HD + g * 8;
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(qp);
+            const f32x4 q1 = *reinterpret_cast<const f32x4*>(qp + 4);
+            float r[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { r[e] = q0[e] * p.scale; r[4 + e] = q1[e] * p.scale; }
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const __bf16 h = (__bf16)r[e];
+                    qf[pl][e] = h;
+                    r[e] -= (float)h;
+                }
+            }
+        }
+        f32x4 st[9];
+#pragma unroll
+        for (int kt = 0; kt < 9; ++kt) {
+            const int key = kt * 16 + li;
+            bf16x8 kf[NP];
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+                kf[pl] = *reinterpret_cast<const bf16x8*>(Kp + (pl * NTOK + key) * HD + ((g ^ kswz(key)) << 3));
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (NP == 2) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1], qf[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0], qf[1], acc, 0, 0, 0);
+            }
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0], qf[0], acc, 0, 0, 0);
+            st[kt] = acc;
+            if (kt % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+        }
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kt = 0; kt < 9; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + g * 4 + r;
+                float sv = st[kt][r] + tab_s[qbase - key - 11 * (key / WS)];
+                if (p.shift > 0) sv += ((int)rid_s[key] != qrid) ? -100.0f : 0.0f;
+                st[kt][r] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 9; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(st[kt][r] - mx);
+                st[kt][r] = e;
+                sum += e;
+            }
+        }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        // O^T = V^T P^T: 5 k-steps of 32 keys (key tiles 2t, 2t+1; the 10th tile does not exist: zero operands)
+        f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            bf16x8 pf[NP];
+            {
+                float r[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { r[e] = st[2 * t][e]; r[4 + e] = (2 * t + 1 < 9) ? st[(2 * t + 1 < 9) ? 2 * t + 1 : 0][e] : 0.f; }
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const __bf16 h = (__bf16)r[e];
+                        pf[pl][e] = h;
+                        r[e] -= (float)h;
+                    }
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                bf16x8 vf[NP];
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) {
+                    const __bf16* vrow = Vt + (pl * HD + dt * 16 + li) * VT_LD + g * 4;
+                    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow + (2 * t) * 16);
+                    bf16x4 hi = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+                    if (2 * t + 1 < 9) hi = *reinterpret_cast<const bf16x4*>(vrow + (2 * t + 1) * 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { vf[pl][e] = lo[e]; vf[pl][4 + e] = hi[e]; }
+                }
+                f32x4 o = dt == 0 ? o0 : o1;
+                if (NP == 2) {
+                    o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[1], pf[0], o, 0, 0, 0);
+                    o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[0], pf[1], o, 0, 0, 0);
+                }
+                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[0], pf[0], o, 0, 0, 0);
+                if (dt == 0) o0 = o; else o1 = o;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (qsrc >= 0) {
+            const float inv = 1.0f / sum;
+            float* op = p.out + (long)qsrc * C + head * HD + g * 4;
+            *reinterpret_cast<f32x4*>(op) = o0 * inv;
+            *reinterpret_cast<f32x4*>(op + 16) = o1 * inv;
+        }
+    }
+}
+
 hipError_t launch_window_attention(const WindowAttnParams& p, hipStream_t s) {
     if (p.C != p.heads * HD || p.Hp % WS || p.Wp % WS || p.Hp < p.H || p.Wp < p.W) return hipErrorInvalidValue;
     if (!(p.shift == 0 || p.shift == WS / 2)) return hipErrorInvalidValue;
     const int nW = (p.Hp / WS) * (p.Wp / WS);
     dim3 grid(p.B * nW, p.heads), block(ATT_THREADS);
-    hipLaunchKernelGGL(window_attention_f32_kernel, grid, block, 0, s, p);
+    if (p.planes == 2) hipLaunchKernelGGL(window_attention_split_kernel<2>, grid, block, 0, s, p);
+    else if (p.planes == 1) hipLaunchKernelGGL(window_attention_split_kernel<1>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(window_attention_f32_kernel, grid, block, 0, s, p);
     return hipGetLastError();
 }
 

@@ -196,3 +196,21 @@ def test_conv2d_split_modes(gpu, mode, tol, B, C, H, W, O, k, p):
         ops.set_compute("f32")
     ref = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=p)
     _close(y, ref.numpy(), tol=tol)
+
+
+@pytest.mark.parametrize("mode,tol", [("f32_split2", 1e-4), ("bf16_operands", 3e-2)])
+@pytest.mark.parametrize("B,H,W,heads,shift", [(1, 12, 12, 2, 0), (2, 24, 24, 3, 6), (1, 16, 16, 2, 6), (1, 32, 20, 6, 6), (1, 4, 4, 1, 6), (1, 64, 64, 24, 6)])
+def test_window_attention_split_modes(gpu, mode, tol, B, H, W, heads, shift):
+    """the bf16-split attention kernel (window_attention_split_kernel) incl. pad tokens, shift mask, odd geometries"""
+    from candle_birefnet_amd import ops
+    C = heads * 32
+    w = _attn_weights(C, heads, seed=10)
+    x = rnd(B, H, W, C, seed=99)
+    ops.set_compute(mode)
+    try:
+        y = ops.window_attention(x, heads, shift, w["attn.qkv.weight"], w["attn.qkv.bias"], w["attn.proj.weight"], w["attn.proj.bias"],
+                                 w["attn.relative_position_bias_table"])
+    finally:
+        ops.set_compute("f32")
+    ref = R.window_attention_block(torch.from_numpy(x).double(), w, "", heads, 12, shift, torch.float64)
+    _close(y, ref.numpy(), tol=tol)
