@@ -85,17 +85,20 @@ static inline float bf16_to_f32(uint16_t h) {
     memcpy(&f, &u, 4);
     return f;
 }
-// error-free split of the packed fp32 matrix into bf16 planes: plane p = RN_bf16(x - sum of the previous planes)
+// error-free split of the packed fp32 matrix [rows][K] into bf16 planes: plane p = RN_bf16(x - sum of the previous planes),
+// stored interleaved per 32-deep K tile: [row][K/32][plane][32] (a (row, K tile) is NP x 64 contiguous bytes)
 static void attach_planes(DeviceOwner& own, GemmW& g, const std::vector<float>& pk, int rows) {
     const int np = g_build_planes;
     if (np <= 0) return;
     const size_t n = pk.size();
+    const size_t K = (size_t)g.K;
     std::vector<uint16_t> planes(n * np);
     for (size_t i = 0; i < n; ++i) {
+        const size_t row = i / K, k = i - row * K;
         float r = pk[i];
         for (int p = 0; p < np; ++p) {
             const uint16_t h = bf16_rne(r);
-            planes[(size_t)p * n + i] = h;
+            planes[(row * (K / 32) + k / 32) * (size_t)np * 32 + (size_t)p * 32 + (k & 31)] = h;
             r -= bf16_to_f32(h);
         }
     }

@@ -424,8 +424,10 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_split_kernel(const GemmParam
         }
     }
     const int wc = tid & 3, wrow = tid >> 2;
-    const long wplane = (long)p.wp_rows * p.K;          // elements per W plane
-    const __bf16* wsrc = reinterpret_cast<const __bf16*>(p.Wp) + (long)(n0 + wrow) * p.K + wc * 8;
+    // W planes are interleaved per 32-deep K tile: [row][K/32][plane][32] bf16, so the NP x 64 bytes a (row, K tile) needs
+    // are contiguous (NP = 2: exactly one 128-byte line; separate planes fetched every line twice: measured 2x L2->L1 traffic)
+    const long wrow_stride = (long)p.K * NP;
+    const __bf16* wsrc = reinterpret_cast<const __bf16*>(p.Wp) + (long)(n0 + wrow) * wrow_stride + wc * 8;
 
     // two staging register sets: tile kt+2 is already in flight while tile kt is multiplied (bytes in flight per CU, not
     // bandwidth, bound this kernel: a bf16-rate K tile lasts a few hundred cycles, an L2/HBM round trip ~1-2 thousand)
@@ -439,7 +441,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_split_kernel(const GemmParam
         for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
             for (int i = 0; i < PB; ++i)
-                qb[pl][i] = *reinterpret_cast<const bf16x8*>(wsrc + pl * wplane + (long)i * WRPP * p.K + k0);
+                qb[pl][i] = *reinterpret_cast<const bf16x8*>(wsrc + (long)i * WRPP * wrow_stride + (long)kt * (NP * 32) + pl * 32);
         if (MODE == GEMM_DENSE) {
 #pragma unroll
             for (int i = 0; i < PA; ++i)
@@ -606,8 +608,9 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
             }
         }
         const int wc = pt % WQ, wrow = pt / WQ;
-        const long wplane = (long)p.wp_rows * p.K;
-        const __bf16* wsrc = reinterpret_cast<const __bf16*>(p.Wp) + (long)(n0 + wrow) * p.K + wc * 8;
+        static_assert(KS == 32, "the interleaved W plane layout is per 32-deep K tile");
+        const long wrow_stride = (long)p.K * NP;         // W planes interleaved per K tile: [row][K/32][plane][32] bf16
+        const __bf16* wsrc = reinterpret_cast<const __bf16*>(p.Wp) + (long)(n0 + wrow) * wrow_stride + wc * 8;
         f32x4 ra[2][PA];
         bf16x8 rb[2][NP][PB];
         float am[2][PA];
@@ -617,7 +620,7 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
             for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
                 for (int i = 0; i < PB; ++i)
-                    qb[pl][i] = *reinterpret_cast<const bf16x8*>(wsrc + pl * wplane + (long)i * WRPP * p.K + k0);
+                    qb[pl][i] = *reinterpret_cast<const bf16x8*>(wsrc + (long)i * WRPP * wrow_stride + (long)(kt0 + t) * (NP * 32) + pl * 32);
             if (MODE == GEMM_DENSE) {
 #pragma unroll
                 for (int i = 0; i < PA; ++i)
