@@ -57,3 +57,31 @@ def test_pieces_vs_torch(gpu):
     out = m.decoder.forward(x, *[parts[k].float().numpy() for k in ("x1", "x2", "x3", "x4s")])
     _gate(out, ref.numpy())
     m.close()
+
+
+@pytest.mark.parametrize("H,W,B,mode,compute", [(96, 160, 1, "reference_cpu", "f32"), (160, 64, 2, "reference_cpu", "f32_split2"),
+                                                (128, 96, 1, "deformable", "f32_split2"), (64, 224, 1, "deformable", "f32")])
+def test_forward_logits_non_square(gpu, H, W, B, mode, compute):
+    """non-square inputs (ragged window padding on one axis, odd half-scale stages) in both deform modes / compute modes"""
+    cb, cfg, w = _build([2, 2, 2, 2], mode)
+    m = cb.BiRefNet.new(cfg, cb.VarBuilder.from_tensors(w), compute=compute)
+    x = cb.synth_input(B, H, W)
+    y = m.forward_logits(x)
+    ref = R.forward_logits(x, w, cfg, torch.float64).numpy()
+    e = _gate(y, ref)
+    assert e < 1e-4
+    m.close()
+
+
+def test_device_resident_io_and_replan(gpu):
+    """device tensors in/out on torch's stream, workspace re-planned when a larger input arrives, results independent of it"""
+    cb, cfg, w = _build([2, 2, 2, 2])
+    m = cb.BiRefNet.new(cfg, cb.VarBuilder.from_tensors(w), max_batch=1, max_size=(64, 64))
+    x64 = cb.synth_input(1, 64, 64)
+    y_small_first = m.forward_logits(torch.from_numpy(x64).cuda()).cpu().numpy()
+    x128 = cb.synth_input(2, 128, 128)
+    y128 = m.forward_logits(torch.from_numpy(x128).cuda())          # forces a re-plan (bigger batch and size)
+    assert y128.is_cuda and y128.shape == (2, 1, 128, 128) and bool(torch.isfinite(y128).all())
+    y_small_again = m.forward_logits(x64)                             # host path after the re-plan
+    np.testing.assert_array_equal(y_small_first, y_small_again)
+    m.close()
