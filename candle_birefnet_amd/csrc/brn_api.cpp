@@ -619,6 +619,45 @@ brn_status brn_deform_conv2d_forward(const float* x, int B, int C, int H, int W,
 // ---- diagnostics -----------------------------------------------------------------------------------------------------
 brn_status brn_gemm_microbench(int M, int N, int K, int tile_cfg, int splitk, int iters, int device, float* ms_per_launch) {
     return guarded([&] {
+        if (tile_cfg >= 130 && tile_cfg < 140) {   // MFMA / VALU SIMD-sharing probe, mode = tile_cfg - 130; returns us per launch
+            ensure_device(device);
+            DeviceOwner own;
+            std::vector<float> z(16, 0.f);
+            float* sink = own.upload(z);
+            hipEvent_t e0, e1;
+            BRN_HIP(hipEventCreate(&e0)); BRN_HIP(hipEventCreate(&e1));
+            BRN_HIP(launch_mfma_valu_probe(M, N, tile_cfg - 130, sink, nullptr));
+            BRN_HIP(hipEventRecord(e0, nullptr));
+            for (int i = 0; i < iters; ++i) BRN_HIP(launch_mfma_valu_probe(M, N, tile_cfg - 130, sink, nullptr));
+            BRN_HIP(hipEventRecord(e1, nullptr));
+            BRN_HIP(hipEventSynchronize(e1));
+            float ms = 0.f;
+            BRN_HIP(hipEventElapsedTime(&ms, e0, e1));
+            ms_per_launch[0] = ms / iters * 1e3f;
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+            return;
+        }
+        if (tile_cfg >= 110 && tile_cfg < 130) {   // LDS-fragment + MFMA consumer-loop probe: 11x = variant 0, 12x = variant 1, x = planes
+            ensure_device(device);
+            DeviceOwner own;
+            std::vector<float> z(16, 0.f);
+            float* sink = own.upload(z);
+            const int np = tile_cfg % 10, variant = tile_cfg >= 120;
+            hipEvent_t e0, e1;
+            BRN_HIP(hipEventCreate(&e0)); BRN_HIP(hipEventCreate(&e1));
+            BRN_HIP(launch_lds_mfma_probe(M, N, np, variant, sink, nullptr));
+            BRN_HIP(hipEventRecord(e0, nullptr));
+            for (int i = 0; i < iters; ++i) BRN_HIP(launch_lds_mfma_probe(M, N, np, variant, sink, nullptr));
+            BRN_HIP(hipEventRecord(e1, nullptr));
+            BRN_HIP(hipEventSynchronize(e1));
+            float ms = 0.f;
+            BRN_HIP(hipEventElapsedTime(&ms, e0, e1));
+            const int npair = np * (np + 1) / 2;
+            const double mfmas = (double)M * 4 * (double)N * 2 * 4 * npair;      // wgs * waves * iters * ksteps * tiles * pairs
+            ms_per_launch[0] = (float)(mfmas * 32768.0 / (ms / iters * 1e-3) / 1e12);   // bf16 TF/s
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+            return;
+        }
         if (tile_cfg == 101 || tile_cfg == 102) {   // bf16 32x32x16 MFMA peak probe (101: 4 accumulators, 102: one dependent chain)
             ensure_device(device);
             DeviceOwner own;
@@ -702,6 +741,19 @@ brn_status brn_gemm_microbench(int M, int N, int K, int tile_cfg, int splitk, in
         BRN_HIP(hipEventElapsedTime(&ms, e0, e1));
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         *ms_per_launch = ms / iters;
+        if (const char* tp = getenv("BRN_GEMM_TRACE")) {   // one more launch with per-workgroup cycle stamps, dumped raw
+            const size_t nwg = (size_t)((M + 127) / 128) * ((N + 127) / 128) * (size_t)std::max(1, pl.splitk);
+            std::vector<unsigned long long> tr(nwg * 256, 0ull);
+            unsigned long long* dtr = nullptr;
+            BRN_HIP(hipMalloc(&dtr, tr.size() * 8));
+            BRN_HIP(hipMemset(dtr, 0, tr.size() * 8));
+            p.trace = dtr;
+            BRN_HIP(launch_gemm(p, pl, ws, nullptr));
+            BRN_HIP(hipDeviceSynchronize());
+            BRN_HIP(hipMemcpy(tr.data(), dtr, tr.size() * 8, hipMemcpyDeviceToHost));
+            (void)hipFree(dtr);
+            if (FILE* f = fopen(tp, "wb")) { fwrite(tr.data(), 8, tr.size(), f); fclose(f); }
+        }
     });
 }
 

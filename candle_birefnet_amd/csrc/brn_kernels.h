@@ -41,6 +41,7 @@ struct GemmParams {
     const void* Wp; int planes; int wp_rows;
     // split-K (filled by launch_gemm from the plan): slices write raw partials to part[slice][M][N]
     int splitk; float* part;
+    unsigned long long* trace;   // diagnostics only: per-workgroup cycle stamps (gemm_split_ws_kernel), null in production
     int abl;   // diagnostics only (brn_gemm_microbench): 1 = no global loads in the K loop, 2 = no LDS staging, 4 = no fragment reads / MFMA
 };
 
@@ -49,6 +50,8 @@ GemmPlan plan_gemm(int M, int N, int K);
 // ws: plan.ws_floats floats of scratch when plan.splitk > 1.  Returns the hipError_t of the launch(es).
 hipError_t launch_gemm(const GemmParams& p, const GemmPlan& plan, float* ws, hipStream_t s);
 
+hipError_t launch_mfma_valu_probe(int blocks, int iters, int mode, float* sink, hipStream_t s);
+hipError_t launch_lds_mfma_probe(int blocks, int iters, int np, int variant, float* sink, hipStream_t s);
 hipError_t launch_mfma_peak_bf16(int blocks, int iters, float* sink, unsigned long long* clk, int nacc, hipStream_t s);
 hipError_t launch_mfma_peak(int blocks, int iters, float* sink, unsigned long long* clk, hipStream_t s);
 

@@ -356,18 +356,32 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int SLD = 40;   // bf16 elements per LDS row
 
+// Error-free split of four fp32 values (times a 0/1 row mask) into NP bf16 planes: plane 0 = RNE bf16(x), plane p+1 = RNE
+// bf16 of what is left.  Written with one-instruction asm pieces on purpose: left to the compiler, the multiplies and
+// subtractions become packed-fp32 instructions (v_pk_mul_f32 / v_pk_fma_f32 with op_sel), and with those this kernel's
+// producer waves stored wrong A rows a few times per 10^5 K tiles while MFMA waves shared their SIMD (always the last 16
+// lanes, always the op_sel'd operand; tools/race_ints.py is the reproducer).  Plain VALU forms are also cheaper beside MFMAs.
+__device__ __forceinline__ float valu_mul(float a, float b) { float r; asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float valu_sub(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ unsigned valu_cvt_pk_bf16(float a, float b) { unsigned r; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 template <int NP>
-__device__ __forceinline__ void split4(const f32x4 v, bf16x4 (&out)[NP]) {
-    f32x4 r = v;
+__device__ __forceinline__ void split4(const f32x4 v, const float mask, bf16x4 (&out)[NP]) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    float r[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = valu_mul(v[e], mask);
 #pragma unroll
     for (int pl = 0; pl < NP; ++pl) {
-        bf16x4 h;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) h[e] = (__bf16)r[e];
-        out[pl] = h;
+        u32x2 h;
+        h[0] = valu_cvt_pk_bf16(r[0], r[1]);
+        h[1] = valu_cvt_pk_bf16(r[2], r[3]);
+        out[pl] = __builtin_bit_cast(bf16x4, h);
         if (pl + 1 < NP) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = r[e] - (float)h[e];
+            for (int q = 0; q < 2; ++q) {
+                r[2 * q] = valu_sub(r[2 * q], __builtin_bit_cast(float, h[q] << 16));
+                r[2 * q + 1] = valu_sub(r[2 * q + 1], __builtin_bit_cast(float, h[q] & 0xffff0000u));
+            }
         }
     }
 }
@@ -465,7 +479,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_split_kernel(const GemmParam
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             bf16x4 sp[NP];
-            split4<NP>(qa[i] * qm[i], sp);
+            split4<NP>(qa[i], qm[i], sp);
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
                 *reinterpret_cast<bf16x4*>(As + (pl * BM + lrow + i * RPP) * SLD + kq * 4) = sp[pl];
@@ -505,7 +519,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_split_kernel(const GemmParam
             }
             // smallest plane products first
 #pragma unroll
-            for (int sum = 2 * (NP - 1) > 2 ? 2 : 2 * (NP - 1); sum >= 0; --sum)
+            for (int sum = NP - 1; sum >= 0; --sum)
 #pragma unroll
                 for (int pa = 0; pa < NP; ++pa) {
                     const int pb = sum - pa;
@@ -528,11 +542,11 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_split_kernel(const GemmParam
     // body for one K tile whose successor sits in register set NXT; the set just consumed (CUR) is refilled 2 tiles ahead
 #define BRN_SPLIT_STEP(KT, CUR, NXT)                                  \
     {                                                                 \
-        if ((KT) + 2 < nk && !(p.abl & 1)) gload((KT) + 2, ra[CUR], rb[CUR], am[CUR]);         \
-        if (!(p.abl & 4)) compute();                                  \
+        if ((KT) + 2 < nk) gload((KT) + 2, ra[CUR], rb[CUR], am[CUR]);         \
+        compute();                                                    \
         __syncthreads();                                              \
         if ((KT) + 1 < nk) {                                          \
-            if (!(p.abl & 2)) lds_store(ra[NXT], rb[NXT], am[NXT]);            \
+            lds_store(ra[NXT], rb[NXT], am[NXT]);            \
             __syncthreads();                                          \
         }                                                             \
     }
@@ -553,7 +567,8 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_split_kernel(const GemmParam
 // registers: at bf16 MFMA rates an exposed LDS read (~250 cycles) per 32-deep K tile (768 MFMA cycles) was a third of the
 // loop (measured by ablation: staging and MFMA phases added up, then the fragment-read stall did).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int MODE, int NP, int KS>   // KS = k elements per LDS stage (32, or 16 to halve the stage when 3 planes must fit twice per CU)
+template <int MODE, int NP, int KS, bool DIAG>   // DIAG: ablation switches + per-K-tile cycle stamps (brn_gemm_microbench only; costs registers)
+// KS = k elements per LDS stage (32, or 16 to halve the stage when 3 planes must fit twice per CU)
 __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) {
     constexpr int BM = 128, BN = 128, WTM = 64, WTN = 64, TM = 2, TN = 2;
     constexpr int SLD = KS + 8;                     // bf16 per LDS row (16-byte pad: conflict-free b128 fragment reads)
@@ -567,6 +582,7 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
     __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int abl = DIAG ? p.abl : 0;
     const bool producer = wave >= 4;
     const int tilesN = (p.N + BN - 1) / BN;
     int swz;
@@ -585,6 +601,16 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
     const int kt0 = slice * kts, nk = min(nk_all, kt0 + kts);
     const int nt = nk > kt0 ? nk - kt0 : 0;         // K tiles of this slice; local tile index t = kt - kt0
 
+    unsigned long long* trc = (DIAG && p.trace) ? p.trace + (long)blockIdx.x * 256 : nullptr;
+    if (trc && (tid == 0 || tid == 256)) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        trc[(tid >> 8) * 8 + 0] = clock64();
+        trc[(tid >> 8) * 8 + 1] = wall_clock64();
+        trc[(tid >> 8) * 8 + 2] = ((unsigned long long)xcc << 32) | hwid;
+    }
     if (producer) {
         const int pt = tid - 256;
         const int kq = pt % AQ, lrow = pt / AQ;
@@ -646,7 +672,7 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
 #pragma unroll
             for (int i = 0; i < PA; ++i) {
                 bf16x4 sp[NP];
-                split4<NP>(qa[i] * qm[i], sp);
+                split4<NP>(qa[i], qm[i], sp);
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl)
                     *reinterpret_cast<bf16x4*>(As + (pl * BM + lrow + i * RPP) * SLD + kq * 4) = sp[pl];
@@ -661,27 +687,33 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
         // prologue: LDS tiles 0 .. AHEAD-1 stored, register sets hold the next two tiles
         if (nt > 0) gload(0, ra[0], rb[0], am[0]);
         if (nt > 1) gload(1, ra[1], rb[1], am[1]);
-        if (nt > 0 && !(p.abl & 2)) lds_store(0, ra[0], rb[0], am[0]);
+        if (nt > 0 && !(abl & 2)) lds_store(0, ra[0], rb[0], am[0]);
         if (nt > 2) gload(2, ra[0], rb[0], am[0]);
         if (AHEAD > 1) {
-            if (nt > 1 && !(p.abl & 2)) lds_store(1, ra[1], rb[1], am[1]);
+            if (nt > 1 && !(abl & 2)) lds_store(1, ra[1], rb[1], am[1]);
             if (nt > 3) gload(3, ra[1], rb[1], am[1]);
         }
+        if (trc && tid == 256) trc[8 + 3] = clock64();
         __syncthreads();
         // step t: store tile t+AHEAD (register set (t+AHEAD)&1), refill that set with tile t+AHEAD+2
 #define BRN_PROD_STEP(T, SET)                                                              \
         {                                                                                  \
+            if (trc && tid == 256 && (T) < 24) trc[16 + (T) * 4 + 0] = clock64();          \
+            if (trc) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (tid == 256 && (T) < 24) trc[16 + (T) * 4 + 3] = clock64(); } \
             if ((T) + AHEAD < nt) {                                                        \
-                if (!(p.abl & 2)) lds_store((T) + AHEAD, ra[SET], rb[SET], am[SET]);                \
-                if ((T) + AHEAD + 2 < nt && !(p.abl & 1)) gload((T) + AHEAD + 2, ra[SET], rb[SET], am[SET]); \
+                if (!(abl & 2)) lds_store((T) + AHEAD, ra[SET], rb[SET], am[SET]);                \
+                if (trc && tid == 256 && (T) < 24) trc[16 + (T) * 4 + 1] = clock64();      \
+                if ((T) + AHEAD + 2 < nt && !(abl & 1)) gload((T) + AHEAD + 2, ra[SET], rb[SET], am[SET]); \
             }                                                                              \
-            __syncthreads();                                                               \
+            if (trc && tid == 256 && (T) < 24) trc[16 + (T) * 4 + 2] = clock64();          \
+            if (!(abl & 16)) __syncthreads();                                            \
         }
         for (int t = 0; t < nt; t += 2) {
             BRN_PROD_STEP(t, AHEAD & 1)
             if (t + 1 < nt) BRN_PROD_STEP(t + 1, (AHEAD + 1) & 1)
         }
 #undef BRN_PROD_STEP
+        if (trc && tid == 256) { trc[8 + 4] = clock64(); trc[8 + 5] = wall_clock64(); }
         return;
     }
 
@@ -709,7 +741,7 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
     auto mfma_all = [&](const bf16x8 (&af)[NP][TM], const bf16x8 (&bf)[NP][TN]) {
         // smallest plane products first
 #pragma unroll
-        for (int sum = 2 * (NP - 1) > 2 ? 2 : 2 * (NP - 1); sum >= 0; --sum)
+        for (int sum = NP - 1; sum >= 0; --sum)
 #pragma unroll
             for (int pa = 0; pa < NP; ++pa) {
                 const int pb = sum - pa;
@@ -723,10 +755,12 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
     };
     bf16x8 fa0[NP][TM], fb0[NP][TN], fa1[NP][TM], fb1[NP][TN];
     __syncthreads();   // prologue barrier: LDS tiles 0 .. AHEAD-1 are complete
+    if (trc && tid == 0) trc[3] = clock64();
     constexpr bool XPREFETCH = NBUF >= 3;   // tile t+1 is complete during step t only with a 3-deep ring
-    if (nt > 0 && !(p.abl & 4)) read_frags(0, 0, fa0, fb0);
+    if (nt > 0 && !(abl & 4)) read_frags(0, 0, fa0, fb0);
     for (int t = 0; t < nt; ++t) {
-        if (!(p.abl & 4)) {
+        if (trc && tid == 0 && t < 24) trc[128 + t * 4 + 0] = clock64();
+        if (!(abl & 4)) {
             if (KSTEPS == 2) {
                 read_frags(t, 1, fa1, fb1);
                 mfma_all(fa0, fb0);
@@ -736,11 +770,14 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
                 mfma_all(fa0, fb0);
             }
         }
-        __syncthreads();
-        if ((!XPREFETCH || KSTEPS == 1) && t + 1 < nt && !(p.abl & 4)) read_frags(t + 1, 0, fa0, fb0);
+        if (trc && tid == 0 && t < 24) trc[128 + t * 4 + 1] = clock64();
+        if (!(abl & 16)) __syncthreads();
+        if ((!XPREFETCH || KSTEPS == 1) && t + 1 < nt && !(abl & 4)) read_frags(t + 1, 0, fa0, fb0);
     }
+    if (trc && tid == 0) trc[4] = clock64();
     // producers have left; the staging LDS is free for the epilogue patches (all LDS reads retired by the last barrier)
     gemm_epilogue<TM, TN, WTM, WTN>(p, acc, m0, n0, wm, wn, lane, slice, reinterpret_cast<float*>(smem_raw) + wave * EPI_WAVE_FLOATS);
+    if (trc && tid == 0) { trc[5] = clock64(); trc[6] = wall_clock64(); }
 }
 
 template <int NP>
@@ -748,8 +785,9 @@ static hipError_t launch_split_ws(const GemmParams& p, hipStream_t s) {
     const int tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128) * p.splitk;
     dim3 grid(tiles), block(512);
     constexpr int KS = 32;                  // (16-deep stages were tried for 3 planes: registers, not LDS, cap residency; slower)
-    if (p.mode == GEMM_DENSE) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, NP, KS>), grid, block, 0, s, p);
-    else if (p.mode == GEMM_CONV_NHWC) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_CONV_NHWC, NP, KS>), grid, block, 0, s, p);
+    if (p.mode == GEMM_DENSE && (p.abl || p.trace)) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, NP, KS, true>), grid, block, 0, s, p);
+    else if (p.mode == GEMM_DENSE) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, NP, KS, false>), grid, block, 0, s, p);
+    else if (p.mode == GEMM_CONV_NHWC) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_CONV_NHWC, NP, KS, false>), grid, block, 0, s, p);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -761,6 +799,179 @@ static hipError_t launch_split_cfg(const GemmParams& p, hipStream_t s) {
     if (p.mode == GEMM_DENSE) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WM, WN, GEMM_DENSE, NP>), grid, block, 0, s, p);
     else if (p.mode == GEMM_CONV_NHWC) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WM, WN, GEMM_CONV_NHWC, NP>), grid, block, 0, s, p);
     else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// diagnostic: the consumer inner loop of the split kernels in isolation — fragments from LDS (ds_read_b128, conflict-free
+// layout of the real kernel), NPAIR MFMAs per (i,j) sub-tile, no global memory, no barriers.  variant 0: reads of a k-step
+// issued right before its MFMAs; variant 1: next k-step's fragments prefetched into a second register set.
+template <int NP, int VARIANT>
+__global__ void __launch_bounds__(256) lds_mfma_probe_kernel(int iters, float* sink) {
+    constexpr int TM = 2, TN = 2, LD = 40;
+    __shared__ __attribute__((aligned(16))) __bf16 smem[NP * 256 * LD];
+    for (int i = threadIdx.x; i < NP * 256 * LD; i += 256) smem[i] = (__bf16)((float)((i * 7) & 15) * 0.0625f - 0.4f);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const __bf16* a_frag = smem + (wm * 64 + (lane & 31)) * LD + (lane >> 5) * 8;
+    const __bf16* b_frag = smem + NP * 128 * LD + (wn * 64 + (lane & 31)) * LD + (lane >> 5) * 8;
+    f32x16 acc[TM][TN];
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto rd = [&](int ks, bf16x8 (&af)[NP][TM], bf16x8 (&bf)[NP][TN]) {
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[pl][i] = *reinterpret_cast<const bf16x8*>(a_frag + (pl * 128 + i * 32) * LD + ks * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[pl][j] = *reinterpret_cast<const bf16x8*>(b_frag + (pl * 128 + j * 32) * LD + ks * 16);
+        }
+    };
+    auto mm = [&](const bf16x8 (&af)[NP][TM], const bf16x8 (&bf)[NP][TN]) {
+#pragma unroll
+        for (int sum = NP - 1; sum >= 0; --sum)
+#pragma unroll
+            for (int pa = 0; pa < NP; ++pa) {
+                const int pb = sum - pa;
+                if (pb < 0 || pb >= NP) continue;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa][i], bf[pb][j], acc[i][j], 0, 0, 0);
+            }
+    };
+    bf16x8 a0[NP][TM], b0[NP][TN], a1[NP][TM], b1[NP][TN];
+    if (VARIANT == 0) {
+        for (int it = 0; it < iters; ++it) {
+            rd(0, a0, b0); mm(a0, b0);
+            rd(1, a1, b1); mm(a1, b1);
+            asm volatile("" ::: "memory");
+        }
+    } else {
+        rd(0, a0, b0);
+        for (int it = 0; it < iters; ++it) {
+            rd(1, a1, b1); mm(a0, b0);
+            rd(0, a0, b0); mm(a1, b1);
+            asm volatile("" ::: "memory");
+        }
+    }
+    float t = 0.f;
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+    if (t == 123.456f) sink[0] = t;
+}
+hipError_t launch_lds_mfma_probe(int blocks, int iters, int np, int variant, float* sink, hipStream_t s) {
+#define BRN_P(NP_, V_) hipLaunchKernelGGL((lds_mfma_probe_kernel<NP_, V_>), dim3(blocks), dim3(256), 0, s, iters, sink)
+    if (np == 1) { if (variant) BRN_P(1, 1); else BRN_P(1, 0); }
+    else if (np == 2) { if (variant) BRN_P(2, 1); else BRN_P(2, 0); }
+    else { if (variant) BRN_P(3, 1); else BRN_P(3, 0); }
+#undef BRN_P
+    return hipGetLastError();
+}
+
+// diagnostic: how MFMA and plain VALU work share a SIMD.  8 waves (two per SIMD) per workgroup.
+//   mode 0: waves 0-3 MFMA only, waves 4-7 exit        mode 1: waves 4-7 VALU only, waves 0-3 exit
+//   mode 2: waves 0-3 MFMA, waves 4-7 VALU (specialised) mode 3: every wave 1/2 of both, VALU interleaved between its MFMAs
+//   mode 4: every wave 1/2 of both, VALU in one block after the MFMAs
+template <int MODE>
+__global__ void __launch_bounds__(512) mfma_valu_probe_kernel(int iters, float* sink) {
+    const int wave = threadIdx.x >> 6;
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    bf16x8 a, b;
+    for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(0.01f * (threadIdx.x & 31) + e); b[e] = (__bf16)(0.5f - 0.03f * e); }
+    float v[6];
+    for (int e = 0; e < 6; ++e) v[e] = 1.0f + 0.001f * threadIdx.x + e;
+    unsigned u[3] = {0, 0, 0};
+#define BRN_MFMA(I) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[I]) : "v"(a), "v"(b))
+    // the split's op mix per pair of elements: cvt_pk, shift, and, 2 sub, cvt_pk  (6 plain VALU)
+#define BRN_VALU6(X, Y, U)                                                             \
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(U) : "v"(X), "v"(Y));          \
+    asm volatile("v_lshlrev_b32 %0, 16, %1\n\tv_sub_f32 %0, %2, %0" : "=&v"(X) : "v"(U), "v"(X)); \
+    asm volatile("v_and_b32 %0, 0xffff0000, %1\n\tv_sub_f32 %0, %2, %0" : "=&v"(Y) : "v"(U), "v"(Y)); \
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(U) : "v"(X), "v"(Y));
+    if (MODE == 0 || MODE == 2) {
+        if (wave < 4) {
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int m = 0; m < 24; ++m) BRN_MFMA(m & 3);
+            }
+        } else if (MODE == 2) {
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int g = 0; g < 12; ++g) { BRN_VALU6(v[(g % 3) * 2], v[(g % 3) * 2 + 1], u[g % 3]) }
+            }
+        }
+    } else if (MODE == 1) {
+        if (wave >= 4) {
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int g = 0; g < 12; ++g) { BRN_VALU6(v[(g % 3) * 2], v[(g % 3) * 2 + 1], u[g % 3]) }
+            }
+        }
+    } else if (MODE >= 5) {
+        // 5: waves 0-3 MFMA + fragment reads   6: waves 4-7 VALU + LDS stores   7: both   (the warp-specialised GEMM's K-tile shape)
+        __shared__ __attribute__((aligned(16))) char lds[40960];
+        const int lane = threadIdx.x & 63;
+        if (wave < 4 && MODE != 6) {
+            const unsigned ra = (unsigned)(size_t)lds + ((wave >> 1) * 64 + (lane & 31)) * 80 + (lane >> 5) * 16;
+            f32x4 f[8];
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[q]) : "v"(ra), "n"(0) );
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int m = 0; m < 12; ++m)
+                        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[m & 3]) : "v"(f[m & 7]), "v"(f[(m + 3) & 7]));
+                }
+            }
+            v[0] += f[0][0];
+        } else if (wave >= 4 && MODE != 5) {
+            const int pt = threadIdx.x - 256;
+            const unsigned wa = (unsigned)(size_t)lds + (pt >> 3) * 80 + (pt & 7) * 8;
+            const unsigned wb = (unsigned)(size_t)lds + 20480 + (pt >> 2) * 80 + (pt & 3) * 16;
+            f32x4 w4 = {v[0], v[1], v[2], v[3]};
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int g = 0; g < 12; ++g) { BRN_VALU6(v[(g % 3) * 2], v[(g % 3) * 2 + 1], u[g % 3]) }
+                unsigned long long d0 = ((unsigned long long)u[0] << 32) | u[1], d1 = ((unsigned long long)u[2] << 32) | u[0];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    asm volatile("ds_write2st64_b64 %0, %1, %2 offset0:%3 offset1:%4" :: "v"(wa), "v"(d0), "v"(d1), "n"(0), "n"(20) : "memory");
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(wb), "v"(w4), "n"(0) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
+    } else if (MODE == 3) {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int m = 0; m < 12; ++m) {
+                BRN_MFMA(m & 3);
+                if (m & 1) { BRN_VALU6(v[(m % 3) * 2], v[(m % 3) * 2 + 1], u[m % 3]) }
+            }
+        }
+    } else {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int m = 0; m < 12; ++m) BRN_MFMA(m & 3);
+#pragma unroll
+            for (int g = 0; g < 6; ++g) { BRN_VALU6(v[(g % 3) * 2], v[(g % 3) * 2 + 1], u[g % 3]) }
+        }
+    }
+#undef BRN_MFMA
+#undef BRN_VALU6
+    float t = v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + (float)(u[0] ^ u[1] ^ u[2]);
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) t += acc[i][r];
+    if (t == 123.456f) sink[0] = t;
+}
+hipError_t launch_mfma_valu_probe(int blocks, int iters, int mode, float* sink, hipStream_t s) {
+#define BRN_P(M_) hipLaunchKernelGGL((mfma_valu_probe_kernel<M_>), dim3(blocks), dim3(512), 0, s, iters, sink)
+    switch (mode) { case 0: BRN_P(0); break; case 1: BRN_P(1); break; case 2: BRN_P(2); break; case 3: BRN_P(3); break; case 5: BRN_P(5); break; case 6: BRN_P(6); break; case 7: BRN_P(7); break; default: BRN_P(4); break; }
+#undef BRN_P
     return hipGetLastError();
 }
 
