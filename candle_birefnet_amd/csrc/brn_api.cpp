@@ -722,7 +722,7 @@ brn_status brn_gemm_microbench(int M, int N, int K, int tile_cfg, int splitk, in
         float* dW = gw.w;
         std::vector<float> hc((size_t)M * N, 0.f);
         float* dC = own.upload(hc);
-        GemmPlan pl = plan_gemm(M, N, K);
+        GemmPlan pl = plan_gemm(M, N, K, gw.wp ? gw.planes : 0);
         if (tile_cfg >= 0) { pl.cfg = tile_cfg; pl.splitk = splitk > 1 ? splitk : 1; pl.ws_floats = pl.splitk > 1 ? (size_t)pl.splitk * M * N : 0; }
         float* ws = nullptr;
         if (pl.ws_floats) { std::vector<float> z(pl.ws_floats, 0.f); ws = own.upload(z); }
@@ -730,6 +730,9 @@ brn_status brn_gemm_microbench(int M, int N, int K, int tile_cfg, int splitk, in
         p.A = dA; p.W = dW; p.C = dC; p.M = M; p.N = N; p.K = K; p.mode = GEMM_DENSE; p.lda = K; p.ldc = N; p.bbias_rows = 1;
         p.Wp = gw.wp; p.planes = gw.planes; p.wp_rows = gw.wp_rows;
         if (const char* ab = getenv("BRN_GEMM_ABLATE")) p.abl = atoi(ab);
+        std::vector<float> hb((size_t)N, 0.1f);
+        if (const char* ac = getenv("BRN_GEMM_ACT")) { p.act = atoi(ac); p.bias = own.upload(hb); }          // epilogue cost probes
+        if (getenv("BRN_GEMM_RES")) { p.R = dC; p.ldr = N; }
         hipEvent_t e0, e1;
         BRN_HIP(hipEventCreate(&e0)); BRN_HIP(hipEventCreate(&e1));
         for (int i = 0; i < 3; ++i) BRN_HIP(launch_gemm(p, pl, ws, nullptr));

@@ -59,7 +59,7 @@ static void fill_epilogue(GemmParams& p, const GemmW& w) {
 
 void run_gemm(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* C, int ldc, int c_coff, const float* R, int ldr,
               int r_coff, const float* bbias, int bbias_rows) {
-    const GemmPlan pl = plan_gemm(M, w.N, w.K);
+    const GemmPlan pl = plan_gemm(M, w.N, w.K, w.wp ? w.planes : 0);
     const size_t mk = c.arena->mark();
     float* ws = pl.ws_floats ? c.arena->alloc(pl.ws_floats) : nullptr;
     c.arena->release(mk);          // scratch is dead as soon as the reduce pass has been enqueued (in-order stream)
@@ -88,7 +88,7 @@ void run_conv(Ctx& c, const GemmW& w, const Map& in, const Map& out, const float
         run_gemm(c, w, in.p + in.coff, M, in.ld, out.p, out.ld, out.coff);
         return;
     }
-    const GemmPlan pl = plan_gemm(M, w.N, w.K);
+    const GemmPlan pl = plan_gemm(M, w.N, w.K, (w.wp && w.mode == GEMM_CONV_NHWC) ? w.planes : 0);
     const size_t mk = c.arena->mark();
     float* ws = pl.ws_floats ? c.arena->alloc(pl.ws_floats) : nullptr;
     c.arena->release(mk);

@@ -46,7 +46,7 @@ struct GemmParams {
 };
 
 struct GemmPlan { int cfg; int splitk; size_t ws_floats; };   // cfg: 0 = 128x128, 1 = 128x64, 2 = 64x64 block tile
-GemmPlan plan_gemm(int M, int N, int K);
+GemmPlan plan_gemm(int M, int N, int K, int planes = 0);   // planes: bf16 planes of the split modes (0 = fp32 kernels)
 // ws: plan.ws_floats floats of scratch when plan.splitk > 1.  Returns the hipError_t of the launch(es).
 hipError_t launch_gemm(const GemmParams& p, const GemmPlan& plan, float* ws, hipStream_t s);
 

@@ -36,8 +36,23 @@ __device__ __forceinline__ f32x4 load4_masked(const float* ptr, bool ok, float& 
 constexpr int BK = 32;
 constexpr int LDS_LD = 36;
 
+// x.gelu_erf() (candle: 0.5 x (1 + erf(x / sqrt 2)), swin.rs:103).  Branch-free, ~20 VALU ops instead of libm's erff
+// (which costs the fc1 epilogues 18 us per 5120x3072 GEMM): erfc(s) = t (c1 + t (c2 + ...)) exp(-s^2), t = 1 / (1 + p s) for
+// s >= 0 (the Abramowitz-Stegun 7.1.26 form, re-fitted to degree 7 against scipy's erfc on [0, 6]), and 1 + erf(x) is taken
+// as erfc(|s|) for x < 0 and 2 - erfc(s) for x >= 0, so neither side cancels.  |gelu error| < 2e-7 absolute over all x in fp32.
 __device__ __forceinline__ float gelu_erf(float x) {
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    const float s = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, s, 1.0f));
+    float q = -0.29582387555232f;
+    q = fmaf(q, t, 1.4920114662361241f);
+    q = fmaf(q, t, -2.0596673810742456f);
+    q = fmaf(q, t, 2.012361787754068f);
+    q = fmaf(q, t, -0.7324354234987704f);
+    q = fmaf(q, t, 0.42581723346182204f);
+    q = fmaf(q, t, 0.15773620453694617f);
+    q = q * t * __expf(-s * s);                     // erfc(s)
+    const float one_plus_erf = x < 0.f ? q : 2.0f - q;
+    return 0.5f * x * one_plus_erf;
 }
 
 // tile id -> (m tile, n tile): N is walked in groups of GN tile columns, M fastest-but-one inside a group, so that while an XCD
@@ -1065,7 +1080,7 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t s) {
 // shared by its resident workgroups, so a launch lasts ~ ceil(tiles / 256 CUs) x (tile area / efficiency of the config).
 // When even the 64x64 tiling leaves most CUs idle (tall-K convs on small maps, half-scale Swin GEMMs at batch 1) the K
 // loop is split so that ~512 workgroups exist.  W is padded to 128 rows so every config may over-read it.
-GemmPlan plan_gemm(int M, int N, int K) {
+GemmPlan plan_gemm(int M, int N, int K, int planes) {
     struct Cand { int cfg, bm, bn; double eff; };
     static const Cand cands[] = {{0, 128, 128, 1.00}, {1, 128, 64, 0.98}, {2, 64, 64, 0.93}, {5, 128, 128, 1.04}, {4, 256, 128, 1.06}};
     GemmPlan pl{2, 1, 0};
@@ -1078,6 +1093,23 @@ GemmPlan plan_gemm(int M, int N, int K) {
     }
     const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
     const int nk = K / BK;
+    if (planes > 0 && N >= 128) {
+        // split-bf16 modes: the warp-specialised 128x128 kernel beats the 4-wave tiles by 1.3-1.5x whenever its tiles are
+        // mostly full (measured, tools/gemm_sk_sweep.py), two workgroups per CU = 512 slots; under ~200 tiles the K loop is
+        // cut so that ~480 workgroups exist, but never below 24 K tiles per slice (the reduce pass costs more than it buys)
+        const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+        const double waste = (double)t128 * 128.0 * 128.0 / ((double)M * N);
+        if (waste <= 1.25) {
+            pl.cfg = 0; pl.splitk = 1; pl.ws_floats = 0;
+            if (t128 < 200) {
+                int s = (int)(480 / t128);
+                if (s > nk / 24) s = nk / 24;
+                if (s > 8) s = 8;
+                if (s > 1) { pl.splitk = s; pl.ws_floats = (size_t)s * M * N; }
+            }
+            return pl;
+        }
+    }
     if (t64 < 384 && nk >= 8) {
         pl.cfg = 2;
         int s = (int)((768 + t64 - 1) / t64);
