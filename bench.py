@@ -121,11 +121,11 @@ def main():
         # HBM-side bytes per launch of the gemm family: PMC counters cannot be read from inside this process; the figure is
         # the committed rocprofv3 measurement of this very command (profiles/README.md), only quoted when the config matches
         traffic, traffic_note = None, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE not collected for this configuration"
-        tj = os.path.join(ROOT, "profiles", "r01_final_gemm_traffic.json")
+        tj = os.path.join(ROOT, "profiles", "r01b_gemm_traffic.json")
         if os.path.exists(tj) and (B, S, args.compute, args.deform_mode) == (1, 1024, "f32_split2", "reference_cpu"):
             t = json.load(open(tj))
             traffic = round((t["hbm_read_gb_x2corrected"] + t["hbm_write_gb"]) * 1e9 / t["gemm_family_dispatches"])
-            traffic_note = ("bytes per launch, gemm family average, from profiles/r01_final_pmc_hbm_b1_1024_split2.csv (FETCH_SIZE x2 "
+            traffic_note = ("bytes per launch, gemm family average, from profiles/r01b_pmc_hbm_b1_1024_split2.csv (FETCH_SIZE x2 "
                             "gfx950 correction + WRITE_SIZE, separate passes); algorithmic bytes per launch = "
                             f"{round(by / n / max(1, launches // n))}")
         roof = {

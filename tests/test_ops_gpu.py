@@ -214,3 +214,26 @@ def test_window_attention_split_modes(gpu, mode, tol, B, H, W, heads, shift):
         ops.set_compute("f32")
     ref = R.window_attention_block(torch.from_numpy(x).double(), w, "", heads, 12, shift, torch.float64)
     _close(y, ref.numpy(), tol=tol)
+
+
+@pytest.mark.parametrize("mode", ["f32_split2", "f32_split3"])
+def test_split_conv_exact_and_repeatable(gpu, mode):
+    """Small-integer data is exact in every bf16 plane, so the split conv must reproduce the integer result bit for bit,
+    every time.  This is the reproducer of a rare wrong-rows fault (packed-fp32 instructions in the staging waves while
+    MFMA waves share their SIMD: 2 rows x 128 columns wrong a few times per 10^5 K tiles); 98 K tiles x 1024 workgroups
+    per run made it show in every run before the fix."""
+    from candle_birefnet_amd import ops
+    B, Cin, H, W, Cout, k, pad = 1, 64, 256, 256, 256, 7, 3
+    c = np.arange(Cin)[:, None, None]
+    x = np.broadcast_to((c % 32 + 1).astype(np.float32), (Cin, H, W))[None].copy()
+    w = np.ones((Cout, Cin, k, k), np.float32)
+    ref = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), padding=pad).numpy()
+    ops.set_compute(mode)
+    try:
+        xd = torch.from_numpy(x).cuda()
+        for _ in range(4):
+            y = ops.conv2d(xd, w, np.zeros(Cout, np.float32), stride=1, padding=pad).cpu().numpy()
+            wrong = int((y.astype(np.float64) != ref).sum())
+            assert wrong == 0, f"{wrong} wrong elements (max |err| {np.abs(y - ref).max()})"
+    finally:
+        ops.set_compute("f32")
