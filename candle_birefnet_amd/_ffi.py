@@ -15,6 +15,7 @@ BRN_F32, BRN_F32_SPLIT3, BRN_F32_SPLIT2, BRN_BF16_OPERANDS = 0, 1, 2, 3
 BRN_DEFORM_REFERENCE_CPU, BRN_DEFORM_DEFORMABLE = 0, 1
 BRN_ACT_NONE, BRN_ACT_RELU, BRN_ACT_GELU_ERF = 0, 1, 2
 
+BRN_ERR_INVALID_ARG, BRN_ERR_MISSING_TENSOR, BRN_ERR_SHAPE, BRN_ERR_NO_DEVICE, BRN_ERR_HIP, BRN_ERR_OOM = 1, 2, 3, 4, 5, 6
 ERR_NAMES = {1: "INVALID_ARG", 2: "MISSING_TENSOR", 3: "SHAPE", 4: "NO_DEVICE", 5: "HIP", 6: "OOM"}
 
 
@@ -73,6 +74,8 @@ _sig("brn_config_lateral_channels", None, C.POINTER(brn_config), C.POINTER(C.c_i
 _sig("brn_config_x4_channels", C.c_int, C.POINTER(brn_config))
 _sig("brn_model_create", C.c_int, C.POINTER(brn_config), C.POINTER(brn_named_tensor), C.c_size_t, C.c_int, C.c_int,
      C.c_int, C.c_int, C.c_int, C.POINTER(_vp))
+_sig("brn_model_create_from_safetensors", C.c_int, C.POINTER(brn_config), C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
+     C.c_int, C.c_int, C.POINTER(_vp))
 _sig("brn_model_destroy", None, _vp)
 _sig("brn_forward_logits", C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp)
 _sig("brn_forward", C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp)
@@ -105,7 +108,7 @@ _sig("brn_gemm_microbench", C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int
 # every symbol include/birefnet_hip.h declares (checked by tests/test_abi.py against the header text)
 DECLARED = [
     "brn_abi_version", "brn_last_error", "brn_build_info", "brn_device_count", "brn_config_default_swin_l",
-    "brn_config_lateral_channels", "brn_config_x4_channels", "brn_model_create", "brn_model_destroy", "brn_forward_logits",
+    "brn_config_lateral_channels", "brn_config_x4_channels", "brn_model_create", "brn_model_create_from_safetensors", "brn_model_destroy", "brn_forward_logits",
     "brn_forward", "brn_model_backbone_forward", "brn_model_squeeze_forward", "brn_model_decoder_forward",
     "brn_model_set_profiling", "brn_model_last_timings", "brn_model_last_kernel_stats", "brn_kernel_family_name",
     "brn_swin_create", "brn_swin_destroy", "brn_swin_forward", "brn_linear_forward", "brn_layer_norm_forward",

@@ -43,23 +43,35 @@ class BiRefNet:
 
     COMPUTE = {"f32": _ffi.BRN_F32, "f32_split3": _ffi.BRN_F32_SPLIT3, "f32_split2": _ffi.BRN_F32_SPLIT2, "bf16_operands": _ffi.BRN_BF16_OPERANDS}
 
-    def __init__(self, config: BiRefNetConfig, vb: VarBuilder, device: int = 0, max_batch: int = 0, max_size=(0, 0), compute: str = "f32"):
+    def __init__(self, config: BiRefNetConfig, vb, device: int = 0, max_batch: int = 0, max_size=(0, 0), compute: str = "f32"):
+        """vb: a VarBuilder, or the path of a .safetensors checkpoint (read natively by the library: the
+        VarBuilder::from_mmaped_safetensors + BiRefNet::new pair of infer_image.rs:35-40)."""
         self.config = config
         self.compute = compute
         self._h = C.c_void_p()
         self._device = device
-        arr, keep = _named_array(vb.tensors_under_prefix())
         cfg = config.to_c()
-        _ffi.check(_ffi.lib.brn_model_create(C.byref(cfg), arr, len(arr), device, self.COMPUTE[compute], int(max_batch),
-                                             int(max_size[0]), int(max_size[1]), C.byref(self._h)))
-        del keep
+        if isinstance(vb, (str, bytes)) or hasattr(vb, "__fspath__"):
+            import os
+            path = os.fsencode(vb)
+            _ffi.check(_ffi.lib.brn_model_create_from_safetensors(C.byref(cfg), path, b"", device, self.COMPUTE[compute], int(max_batch),
+                                                                  int(max_size[0]), int(max_size[1]), C.byref(self._h)))
+        else:
+            arr, keep = _named_array(vb.tensors_under_prefix())
+            _ffi.check(_ffi.lib.brn_model_create(C.byref(cfg), arr, len(arr), device, self.COMPUTE[compute], int(max_batch),
+                                                 int(max_size[0]), int(max_size[1]), C.byref(self._h)))
+            del keep
         self.backbone = _Piece(self, "backbone")
         self.squeeze_module = _Piece(self, "squeeze")
         self.decoder = _Piece(self, "decoder")
 
     @staticmethod
-    def new(config: BiRefNetConfig, vb: VarBuilder, **kw):
+    def new(config: BiRefNetConfig, vb, **kw):
         return BiRefNet(config, vb, **kw)
+
+    @staticmethod
+    def from_safetensors(config: BiRefNetConfig, path, **kw):
+        return BiRefNet(config, path, **kw)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:

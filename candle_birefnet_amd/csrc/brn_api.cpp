@@ -253,6 +253,19 @@ brn_status brn_model_create(const brn_config* cfg, const brn_named_tensor* weigh
         *out = h.release();
     });
 }
+brn_status brn_model_create_from_safetensors(const brn_config* cfg, const char* path, const char* prefix, int device, brn_dtype dt,
+                                            int max_batch, int max_h, int max_w, brn_model** out) {
+    brn_status st = guarded([&] {
+        if (!cfg || !path || !out) fail(BRN_ERR_INVALID_ARG, "null argument");
+        *out = nullptr;
+    });
+    if (st != BRN_OK) return st;
+    SafetensorsFile f;
+    std::vector<brn_named_tensor> named;
+    st = guarded([&] { f.open(path); named = f.named(prefix); if (named.empty()) fail(BRN_ERR_MISSING_TENSOR, "no tensor under prefix '%s' in '%s'", prefix ? prefix : "", path); });
+    if (st != BRN_OK) return st;
+    return brn_model_create(cfg, named.data(), named.size(), device, dt, max_batch, max_h, max_w, out);   // copies; the mapping goes with f
+}
 void brn_model_destroy(brn_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->m.device);

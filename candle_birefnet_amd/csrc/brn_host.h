@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdarg.h>
 #include <string>
+#include <deque>
 #include <vector>
 #include <unordered_map>
 #include <stdexcept>
@@ -126,6 +127,20 @@ struct WeightTable {
     std::unordered_map<std::string, const brn_named_tensor*> map;
     WeightTable(const brn_named_tensor* w, size_t n);
     const brn_named_tensor* get(const std::string& name, std::initializer_list<int64_t> shape) const;
+};
+
+// a memory-mapped .safetensors file as brn_named_tensor views (brn_safetensors.cpp)
+struct SafetensorsFile {
+    struct Entry { std::string name; std::vector<int64_t> shape; const float* data = nullptr; };
+    void* map = nullptr; size_t map_len = 0;
+    std::vector<Entry> entries;
+    std::deque<std::vector<float>> converted;       // F16 / BF16 (or misaligned F32) tensors widened to fp32
+    SafetensorsFile() = default;
+    SafetensorsFile(const SafetensorsFile&) = delete;
+    SafetensorsFile& operator=(const SafetensorsFile&) = delete;
+    ~SafetensorsFile();
+    void open(const char* path);
+    std::vector<brn_named_tensor> named(const char* prefix) const;   // views valid while *this lives; names have prefix stripped
 };
 
 struct DeviceOwner {     // every hipMalloc of a model, freed together

@@ -114,6 +114,14 @@ int brn_config_x4_channels(const brn_config* cfg);
 brn_status brn_model_create(const brn_config* cfg, const brn_named_tensor* weights, size_t n_weights,
                             int device_ordinal, brn_dtype compute_dtype,
                             int max_batch, int max_h, int max_w, brn_model** out);
+/* VarBuilder::from_mmaped_safetensors(&[path], DType::F32, &device) + BiRefNet::new(config, vb) in one call
+ * (infer_image.rs:35-40).  The file is memory-mapped and parsed natively (8-byte LE header length, JSON index, raw LE
+ * tensors); F32 is read in place, F16 / BF16 are widened to fp32 as candle's VarBuilder does for DType::F32.  Tensor names
+ * are looked up below `prefix` ("" or NULL for a full checkpoint).  Errors as brn_model_create, plus BRN_ERR_INVALID_ARG for
+ * an unreadable or malformed file. */
+brn_status brn_model_create_from_safetensors(const brn_config* cfg, const char* path, const char* prefix,
+                                            int device_ordinal, brn_dtype compute_dtype,
+                                            int max_batch, int max_h, int max_w, brn_model** out);
 void brn_model_destroy(brn_model* m);
 
 /* BiRefNet::forward_logits (birefnet.rs:412-461): x [B,3,H,W] -> logits [B,1,H,W] (pre-sigmoid).

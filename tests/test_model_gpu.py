@@ -85,3 +85,26 @@ def test_device_resident_io_and_replan(gpu):
     y_small_again = m.forward_logits(x64)                             # host path after the re-plan
     np.testing.assert_array_equal(y_small_first, y_small_again)
     m.close()
+
+
+def test_model_from_safetensors_file_matches_in_memory(gpu, tmp_path):
+    """brn_model_create_from_safetensors (infer_image.rs:35-40) = brn_model_create on the same tensors, bit for bit; an F16
+    checkpoint is widened to fp32 exactly as VarBuilder(DType::F32) does."""
+    from safetensors.numpy import save_file
+    cb, cfg, w = _build([1, 1, 1, 1])
+    x = cb.synth_input(1, 64, 64)
+    p32 = str(tmp_path / "m32.safetensors")
+    save_file(w, p32)
+    y_mem = cb.BiRefNet.new(cfg, cb.VarBuilder.from_tensors(w)).forward_logits(x)
+    y_file = cb.BiRefNet.from_safetensors(cfg, p32).forward_logits(x)
+    np.testing.assert_array_equal(y_file, y_mem)
+    w16 = {k: v.astype(np.float16) for k, v in w.items()}
+    p16 = str(tmp_path / "m16.safetensors")
+    save_file(w16, p16)
+    y16_file = cb.BiRefNet.from_safetensors(cfg, p16).forward_logits(x)
+    y16_mem = cb.BiRefNet.new(cfg, cb.VarBuilder.from_tensors({k: v.astype(np.float32) for k, v in w16.items()})).forward_logits(x)
+    np.testing.assert_array_equal(y16_file, y16_mem)
+    with pytest.raises(cb.BrnError, match="MISSING_TENSOR"):
+        small = {k: v for k, v in w.items() if not k.startswith("decoder.conv_out1")}
+        save_file(small, str(tmp_path / "bad.safetensors"))
+        cb.BiRefNet.from_safetensors(cfg, str(tmp_path / "bad.safetensors"))

@@ -19,3 +19,49 @@ def test_varbuilder_from_safetensors_roundtrip(tmp_path):
         for part in head.split("."):
             b = b.pp(part)
         np.testing.assert_array_equal(b.get(s, leaf), w[n])
+
+
+def _create_from_file(path, cfg=None):
+    import ctypes as C
+    import candle_birefnet_amd as cb
+    from candle_birefnet_amd import _ffi
+    cfg = cfg or cb.BiRefNetConfig()
+    h = C.c_void_p()
+    c = cfg.to_c()
+    st = _ffi.lib.brn_model_create_from_safetensors(C.byref(c), str(path).encode(), b"", 0, _ffi.BRN_F32, 0, 0, 0, C.byref(h))
+    return st, (_ffi.lib.brn_last_error() or b"").decode()
+
+
+def test_native_loader_rejects_missing_and_malformed_files(tmp_path):
+    """brn_model_create_from_safetensors: file errors surface as BRN_ERR_INVALID_ARG with a message, before any device use."""
+    from candle_birefnet_amd import _ffi
+    st, msg = _create_from_file(tmp_path / "nope.safetensors")
+    assert st == _ffi.BRN_ERR_INVALID_ARG and "cannot open" in msg
+    p = tmp_path / "short.safetensors"
+    p.write_bytes(b"\x10\x00\x00")
+    st, msg = _create_from_file(p)
+    assert st == _ffi.BRN_ERR_INVALID_ARG and "not a safetensors file" in msg
+    p = tmp_path / "liar.safetensors"
+    p.write_bytes((1 << 40).to_bytes(8, "little") + b"{}")
+    st, msg = _create_from_file(p)
+    assert st == _ffi.BRN_ERR_INVALID_ARG and "header length" in msg
+    p = tmp_path / "offsets.safetensors"
+    hdr = b'{"a":{"dtype":"F32","shape":[4],"data_offsets":[0,64]}}'
+    p.write_bytes(len(hdr).to_bytes(8, "little") + hdr + b"\0" * 16)
+    st, msg = _create_from_file(p)
+    assert st == _ffi.BRN_ERR_INVALID_ARG and "outside the file" in msg
+
+
+def test_native_loader_parses_then_needs_a_device_or_a_tensor(tmp_path):
+    """A well-formed file gets past the parser: without the checkpoint's tensors the error names the missing one (candle: Err
+    from vb.get); on a box without a GPU the call stops at BRN_ERR_NO_DEVICE — there is no CPU fallback behind this entry."""
+    import torch
+    from safetensors.numpy import save_file
+    from candle_birefnet_amd import _ffi
+    p = str(tmp_path / "tiny.safetensors")
+    save_file({"bb.patch_embed.proj.bias": np.zeros(192, np.float32), "unrelated": np.ones((2, 3), np.float16)}, p)
+    st, msg = _create_from_file(p)
+    if torch.cuda.is_available():
+        assert st == _ffi.BRN_ERR_MISSING_TENSOR and "bb." in msg
+    else:
+        assert st == _ffi.BRN_ERR_NO_DEVICE
