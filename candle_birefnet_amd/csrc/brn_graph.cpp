@@ -373,15 +373,14 @@ void decoder_forward(Ctx& c, const Model& m, const float* img, int B, int H, int
     ipt_block(c, d.ipt[1], img, B, H, W, h1, w1, 48, d1.window(384, 96));
     Map p1 = new_map(c, B, h1, w1, 192);
     decblk_forward(c, d.dec[3], d1, p1, dm);
-    // head (birefnet.rs:372-375): q = <p1, w[0:192]> at 1/4 res; t = composed 3x3 stencil over ipt_blk1.conv1(x)
+    // head (birefnet.rs:372-375): q = <p1, w[0:192]> at 1/4 res; t = the whole ipt_blk1 branch (conv1 -> conv_out -> its
+    // slice of conv_out1) as one composed 5x5 stencil on the image (brn_weights.cpp): no 64-channel 1024^2 map exists
     float* q = c.arena->alloc((size_t)B * h1 * w1);
     float* tl = c.arena->alloc((size_t)B * H * W);
-    Map u = new_map(c, B, H, W, 64);
-    run_conv_nchw(c, d.ipt[0].conv1, img, B, H, W, u);
     if (!c.dry) {
-        Bracket b(c, FAM_ELEMENTWISE, 2.0 * B * H * (double)W * 576, 4.0 * B * H * (double)W * 65);
+        Bracket b(c, FAM_ELEMENTWISE, 2.0 * B * H * (double)W * 75, 4.0 * B * H * (double)W * 5);
         BRN_LAUNCH(launch_pixel_dot(p1.p, B * h1 * w1, 192, p1.ld, p1.coff, d.out_w, 0.f, q, c.stream));
-        BRN_LAUNCH(launch_conv3x3_to1(u.p, B, H, W, 64, 64, d.tail_w, d.tail_b, tl, c.stream));
+        BRN_LAUNCH(launch_head_stencil5x5(img, B, H, W, d.head_k, d.head_b, tl, c.stream));
         BRN_LAUNCH(launch_final_head(q, B, h1, w1, tl, d.out_b, H, W, apply_sigmoid, out, c.stream));
     }
     c.arena->release(mk);

@@ -116,6 +116,7 @@ struct SimpleConvsW { GemmW conv1, conv_out; };
 struct DecoderW {
     SimpleConvsW ipt[5];   // ipt_blk1..5 (ipt[0] = ipt_blk1: conv1 only, conv_out is composed into tail_w)
     float* tail_w = nullptr; float tail_b = 0.f;   // [9][64]: conv_out1[192:240] o ipt_blk1.conv_out
+    float* head_k = nullptr; float* head_b = nullptr;   // [3x3 border cases][5][5][3] + [9]: that stencil o ipt_blk1.conv1 (see brn_weights.cpp)
     DecBlkW dec[4];        // decoder_block4,3,2,1
     GemmW lat[3];          // lateral_block4,3,2
     GemmW gdt[3];          // gdt_convs_4,3,2 (conv + BN + ReLU)

@@ -111,6 +111,8 @@ hipError_t launch_final_head(const float* q, int B, int h, int w, const float* t
 // 3x3 conv, pad 1, of a 64-channel channels-last map to one channel (composed ipt_blk1.conv_out o conv_out1 slice)
 hipError_t launch_conv3x3_to1(const float* x, int B, int H, int W, int C, int ldx, const float* w, float bias,
                               float* y, hipStream_t s);
+// t = stencil5x5(x): the composed ipt_blk1 head on the NCHW image [B,3,H,W]; k = [9 border cases][5][5][3], bias = [9]
+hipError_t launch_head_stencil5x5(const float* img, int B, int H, int W, const float* k, const float* bias, float* y, hipStream_t s);
 // y = sigmoid(x)
 hipError_t launch_sigmoid(const float* x, size_t n, float* y, hipStream_t s);
 // modulator epilogue for deformable mode: columns [c0,c1) of rows get 2/(1+exp(-x))   (aspp.rs:173-174)

@@ -411,6 +411,40 @@ void build_decoder_weights(const WeightTable& wt, const std::string& p, const br
         for (int o = 0; o < ipt_out[0]; ++o) tb += (double)ow[dec_out[3] + o] * (double)b2[o];
         out.tail_w = own.upload(tw);
         out.tail_b = (float)tb;
+        // One level further: ipt_blk1.conv1 (3x3, 3 -> 64, pad 1, bias b1) feeds that stencil with nothing in between
+        // (SimpleConvs has no activation, decoder.rs:52), so t = stencil3x3(conv1(x)) is ONE 5x5, 3 -> 1 stencil on the image:
+        //   t(p) = tb + sum_{d in D(p)} sum_ci tw[d][ci] * (b1[ci] + sum_e sum_c W1[ci][c][e] * x[c][p+d+e])
+        // where D(p) = the taps d of the outer 3x3 whose centre p+d lies inside the image (the outer conv zero-pads conv1's
+        // OUTPUT, it does not extend it): 3 x 3 border cases (first / inner / last row, same for columns), each with its own
+        // composed kernel K[f = d+e][c] and bias.  x itself is zero-padded, as conv1 does.  fp64 accumulation on the host.
+        const float* w1 = wt.get(p + "ipt_blk1.conv1.weight", {64, 3, 3, 3})->data;
+        const float* b1 = wt.get(p + "ipt_blk1.conv1.bias", {64})->data;
+        std::vector<float> hk(9 * 75), hb(9);
+        for (int cy = 0; cy < 3; ++cy)
+            for (int cx = 0; cx < 3; ++cx) {
+                std::vector<double> K(75, 0.0);
+                double bias = tb;
+                for (int dy = -1; dy <= 1; ++dy) {
+                    if ((cy == 0 && dy < 0) || (cy == 2 && dy > 0)) continue;
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        if ((cx == 0 && dx < 0) || (cx == 2 && dx > 0)) continue;
+                        const int t = (dy + 1) * 3 + (dx + 1);
+                        for (int ci = 0; ci < 64; ++ci) {
+                            const double a = tw[t * 64 + ci];
+                            bias += a * (double)b1[ci];
+                            for (int c = 0; c < 3; ++c)
+                                for (int ey = -1; ey <= 1; ++ey)
+                                    for (int ex = -1; ex <= 1; ++ex)
+                                        K[((dy + ey + 2) * 5 + (dx + ex + 2)) * 3 + c] +=
+                                            a * (double)w1[(((size_t)ci * 3 + c) * 3 + (ey + 1)) * 3 + (ex + 1)];
+                        }
+                    }
+                }
+                for (int i = 0; i < 75; ++i) hk[(cy * 3 + cx) * 75 + i] = (float)K[i];
+                hb[cy * 3 + cx] = (float)bias;
+            }
+        out.head_k = own.upload(hk);
+        out.head_b = own.upload(hb);
     }
 }
 

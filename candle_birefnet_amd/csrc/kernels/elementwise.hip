@@ -356,6 +356,43 @@ __global__ void conv3x3_to1_kernel(const float* __restrict__ x, int B, int H, in
         if (sub == 0) y[pix] = acc + bias;
     }
 }
+// composed ipt_blk1 head (brn_weights.cpp): one thread per output pixel, 75 taps on the 3 image planes (zero outside), the
+// kernel of the pixel's border case read through the scalar cache (uniform per wave except in the 1-pixel frame)
+__global__ void __launch_bounds__(256) head_stencil5x5_kernel(const float* __restrict__ img, int B, int H, int W,
+                                                              const float* __restrict__ k, const float* __restrict__ bias,
+                                                              float* __restrict__ y) {
+    const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    if (ox >= W || oy >= H) return;
+    const int cs = (oy == 0 ? 0 : (oy == H - 1 ? 2 : 1)) * 3 + (ox == 0 ? 0 : (ox == W - 1 ? 2 : 1));
+    const float* kk = k + cs * 75;
+    const float* xb = img + (size_t)b * 3 * H * W;
+    float acc = bias[cs];
+#pragma unroll
+    for (int fy = 0; fy < 5; ++fy) {
+        const int iy = oy + fy - 2;
+        if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+        for (int fx = 0; fx < 5; ++fx) {
+            const int ix = ox + fx - 2;
+            if ((unsigned)ix >= (unsigned)W) continue;
+            const size_t o = (size_t)iy * W + ix;
+            const float* kf = kk + (fy * 5 + fx) * 3;
+            acc = fmaf(xb[o], kf[0], acc);
+            acc = fmaf(xb[(size_t)H * W + o], kf[1], acc);
+            acc = fmaf(xb[2 * (size_t)H * W + o], kf[2], acc);
+        }
+    }
+    y[((size_t)b * H + oy) * W + ox] = acc;
+}
+hipError_t launch_head_stencil5x5(const float* img, int B, int H, int W, const float* k, const float* bias, float* y, hipStream_t s) {
+    if (B <= 0 || H < 2 || W < 2) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((W + 63) / 64), (unsigned)((H + 3) / 4), (unsigned)B), block(256);
+    hipLaunchKernelGGL(head_stencil5x5_kernel, grid, block, 0, s, img, B, H, W, k, bias, y);
+    return hipGetLastError();
+}
+
 hipError_t launch_conv3x3_to1(const float* x, int B, int H, int W, int C, int ldx, const float* w, float bias,
                               float* y, hipStream_t s) {
     if (C != 64) return hipErrorInvalidValue;
