@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--deform-mode", default="reference_cpu", choices=["reference_cpu", "deformable"])
     ap.add_argument("--compute", default="f32_split2", choices=list(MODES),
                     help="arithmetic of the contraction kernels (include/birefnet_hip.h brn_dtype)")
-    ap.add_argument("--also", default="f32", help="comma list of other compute modes to time briefly on rank 0 at N=1 ('' = none)")
+    ap.add_argument("--also", default="f32,f32_split3", help="comma list of other compute modes to time briefly on rank 0 at N=1 ('' = none)")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra steps with per-launch HIP events for the roofline block")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off", "on"])
     ap.add_argument("--cpu-baseline-size", type=int, default=0, help="image side for the CPU oracle sample (0 = choose)")
