@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbirefnet_hip.so")
+LIB_PATH = os.environ.get("BRN_LIB_PATH") or os.path.join(_HERE, "libbirefnet_hip.so")   # override: A/B runs of two builds
 
 BRN_OK = 0
 BRN_MEM_HOST, BRN_MEM_DEVICE = 0, 1

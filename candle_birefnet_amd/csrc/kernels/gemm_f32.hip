@@ -573,6 +573,71 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_split_kernel(const GemmParam
     gemm_epilogue<TM, TN, WTM, WTN>(p, acc, m0, n0, wm, wn, lane, slice, reinterpret_cast<float*>(smem_raw) + wave * EPI_WAVE_FLOATS);
 }
 
+// Workgroup-wide epilogue of the warp-specialised kernels: the C tile sits row-major in LDS (ld floats per row); 512 threads,
+// thread t owns columns 4*(t&31).. of rows (t>>5) + 16*pass.  Same arithmetic, in the same order, as gemm_epilogue.
+template <int BM, int BN, int LD>
+__device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, const float* ctile, int m0, int n0, int tid, int slice) {
+    static_assert(BN == 128, "32 float4 columns per row");
+    const int c4 = (tid & 31) * 4, r0 = tid >> 5;
+    const int n = n0 + c4;
+    if (n >= p.N) return;
+    const bool split = p.splitk > 1;
+    float* part = split ? p.part + (long)slice * p.M * p.N : nullptr;
+    const bool vec = split ? ((p.N & 3) == 0)
+                           : (((p.N | p.ldc | p.c_coff) & 3) == 0 && (!p.R || ((p.ldr | p.r_coff) & 3) == 0));
+    f32x4 bias = zero4(), sc = {1.f, 1.f, 1.f, 1.f}, sh = zero4();
+    if (!split) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (n + e < p.N) {
+                if (p.bias) bias[e] = p.bias[n + e];
+                if (p.scale) { sc[e] = p.scale[n + e]; sh[e] = p.shift[n + e]; }
+            }
+        }
+    }
+#pragma unroll 2
+    for (int ps = 0; ps < BM / 16; ++ps) {
+        const int row = ps * 16 + r0;
+        const int m = m0 + row;
+        if (m >= p.M) break;
+        f32x4 v = *reinterpret_cast<const f32x4*>(ctile + row * LD + c4);
+        if (split) {
+            float* dst = part + (long)m * p.N + n;
+            if (vec) *reinterpret_cast<f32x4*>(dst) = v;
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (n + e < p.N) dst[e] = v[e];
+            }
+            continue;
+        }
+        v = v + bias;
+        if (p.bbias) {
+            const float* bp = p.bbias + (long)(m / p.bbias_rows) * p.N + n;
+            if (vec) v = v + *reinterpret_cast<const f32x4*>(bp);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += bp[e];
+            }
+        }
+        if (p.scale) v = v * sc + sh;
+        v = act4(v, p.act);
+        float* dst = p.C + (long)m * p.ldc + p.c_coff + n;
+        if (vec) {
+            if (p.R) v = v + *reinterpret_cast<const f32x4*>(p.R + (long)m * p.ldr + p.r_coff + n);
+            *reinterpret_cast<f32x4*>(dst) = v;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (n + e < p.N) {
+                    float t = v[e];
+                    if (p.R) t += p.R[(long)m * p.ldr + p.r_coff + n + e];
+                    dst[e] = t;
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // gemm_split_ws_kernel — warp-specialised form of gemm_split_kernel for the 128x128 tile: 8 waves, two per SIMD.
 // Waves 0-3 (consumers) own the 2x2 grid of 64x64 sub-tiles: fragment reads + MFMA only.  Waves 4-7 (producers) stage:
@@ -592,7 +657,8 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
     constexpr int AQ = KS / 4, RPP = 256 / AQ, PA = BM / RPP;   // producers: 256 threads, AQ float4 per KS-float row
     constexpr int WQ = KS / 8, WRPP = 256 / WQ, PB = BN / WRPP; // WQ 16-byte chunks per KS-bf16 row
     constexpr int BUF = NP * (BM + BN) * SLD;       // bf16 elements per LDS buffer
-    constexpr int SMEM_MAIN = NBUF * BUF * 2, SMEM_EPI = 4 * EPI_WAVE_FLOATS * 4;   // bytes
+    constexpr int EP_LD = BN + 4;                   // floats per row of the epilogue's LDS image of the C tile
+    constexpr int SMEM_MAIN = NBUF * BUF * 2, SMEM_EPI = BM * EP_LD * 4;   // bytes
     __shared__ __attribute__((aligned(16))) char smem_raw[SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI];
     __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);
 
@@ -626,6 +692,7 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
         trc[(tid >> 8) * 8 + 1] = wall_clock64();
         trc[(tid >> 8) * 8 + 2] = ((unsigned long long)xcc << 32) | hwid;
     }
+    f32x16 acc[TM][TN];
     if (producer) {
         const int pt = tid - 256;
         const int kq = pt % AQ, lrow = pt / AQ;
@@ -729,11 +796,8 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
         }
 #undef BRN_PROD_STEP
         if (trc && tid == 256) { trc[8 + 4] = clock64(); trc[8 + 5] = wall_clock64(); }
-        return;
-    }
-
+    } else {
     // ---- consumers ----
-    f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -790,8 +854,24 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
         if ((!XPREFETCH || KSTEPS == 1) && t + 1 < nt && !(abl & 4)) read_frags(t + 1, 0, fa0, fb0);
     }
     if (trc && tid == 0) trc[4] = clock64();
-    // producers have left; the staging LDS is free for the epilogue patches (all LDS reads retired by the last barrier)
-    gemm_epilogue<TM, TN, WTM, WTN>(p, acc, m0, n0, wm, wn, lane, slice, reinterpret_cast<float*>(smem_raw) + wave * EPI_WAVE_FLOATS);
+    // the staging LDS is dead (every fragment read retired at the last barrier): the consumers lay their accumulators down as a
+    // row-major image of the C tile
+    float* ctile = reinterpret_cast<float*>(smem_raw);
+    {
+        const int col = lane & 31, rhalf = (lane >> 5) * 4;      // C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ctile[(wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf) * EP_LD + wn * WTN + j * 32 + col] = acc[i][j][r];
+    }
+    }   // consumers
+    // ---- epilogue, all eight waves: the producers have nothing left to do, and a 4-wave epilogue was 5-11 us of store-issue
+    // latency per tile.  Each pass moves 16 rows x 512 B: one wave = two full rows, float4 per lane ----
+    __syncthreads();
+    gemm_epilogue_tile<BM, BN, EP_LD>(p, reinterpret_cast<const float*>(smem_raw), m0, n0, tid, slice);
     if (trc && tid == 0) { trc[5] = clock64(); trc[6] = wall_clock64(); }
 }
 
