@@ -37,8 +37,8 @@ GEMM_FAMILIES = ("gemm_dense", "gemm_conv_nhwc", "gemm_gather_nchw", "gemm_defor
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--deform-mode", default="reference_cpu", choices=["reference_cpu", "deformable"])

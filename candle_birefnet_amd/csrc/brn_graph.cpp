@@ -166,21 +166,23 @@ static void swin_attention_multi(Ctx& c, const SwinBlockW& blk, const float* xn,
     float* qkv = c.arena->alloc((size_t)M * 3 * C);
     float* att = c.arena->alloc((size_t)M * C);
     run_gemm(c, blk.qkv, xn, M, C, qkv, 3 * C, 0);                   // swin.rs:217 (pad rows are synthesised by the kernel)
-    size_t off = 0;
-    for (int k = 0; k < nin; ++k) {
-        const int Mk = B * hs[k] * wsz[k];
-        if (!c.dry) {
-            WindowAttnParams p{};
+    if (!c.dry) {
+        // one launch for all maps of the pass (full + half scale): fewer ramps and tails than one launch per geometry
+        WindowAttnParams ps[2]{};
+        size_t off = 0;
+        double nwin = 0.0;
+        for (int k = 0; k < nin; ++k) {
+            WindowAttnParams& p = ps[k];
             p.qkv = qkv + off * 3 * C; p.qkv_bias = blk.qkv.bias; p.rel_table = blk.rel_table; p.out = att + off * C;
             p.B = B; p.H = hs[k]; p.W = wsz[k]; p.C = C; p.heads = blk.heads;
             p.Hp = roundup(hs[k], 12); p.Wp = roundup(wsz[k], 12);   // swin.rs:359-360
             p.shift = shift; p.scale = 1.0f / sqrtf(32.0f);          // head_dim^-0.5 (swin.rs:134)
             p.planes = (blk.qkv.planes == 2 || blk.qkv.planes == 1) ? blk.qkv.planes : 0;
-            const double nwin = (double)B * (p.Hp / 12) * (p.Wp / 12) * blk.heads;
-            Bracket b(c, FAM_ATTENTION, nwin * 2.0 * 2.0 * 144 * 144 * 32, 4.0 * ((double)Mk * 4 * C), Mk, C, shift);
-            BRN_LAUNCH(launch_window_attention(p, c.stream));
+            nwin += (double)B * (p.Hp / 12) * (p.Wp / 12) * blk.heads;
+            off += (size_t)B * hs[k] * wsz[k];
         }
-        off += Mk;
+        Bracket b(c, FAM_ATTENTION, nwin * 2.0 * 2.0 * 144 * 144 * 32, 4.0 * ((double)M * 4 * C), M, C, shift);
+        BRN_LAUNCH(launch_window_attention2(ps[0], nin > 1 ? &ps[1] : nullptr, c.stream));
     }
     run_gemm(c, blk.proj, att, M, C, y, C, 0, residual, C, 0);      // swin.rs:310 (+ shortcut, swin.rs:406)
     c.arena->release(mk);

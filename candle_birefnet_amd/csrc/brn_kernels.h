@@ -79,6 +79,8 @@ struct WindowAttnParams {
     int planes;           // 0: fp32 MFMA kernel (modes f32, f32_split3); 2 / 1: bf16-split kernel (f32_split2 / bf16_operands)
 };
 hipError_t launch_window_attention(const WindowAttnParams& p, hipStream_t s);
+// two maps of the same stage in one launch (p2 may be null)
+hipError_t launch_window_attention2(const WindowAttnParams& p, const WindowAttnParams* p2, hipStream_t s);
 
 // ---- data movement / elementwise (HBM-bound) ------------------------------------------------------------
 // bilinear, align_corners=true, channels-last window -> window; optional accumulate (y += )

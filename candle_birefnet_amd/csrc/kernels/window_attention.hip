@@ -32,7 +32,12 @@ constexpr int HD = 32;
 constexpr int KV_LD = 36;          // floats per LDS row of K and V
 constexpr int ATT_THREADS = 192;   // 3 waves, 3 query tiles each
 
-__global__ void __launch_bounds__(ATT_THREADS) window_attention_f32_kernel(const WindowAttnParams p) {
+// Both kernels take TWO geometries (the full- and the half-scale map of a co-batched backbone pass, same C / heads / shift):
+// blocks [0, nblk0) work on pa, the rest on pb — one launch, one ramp and one tail instead of two (the half-scale launch alone
+// fills a fifth of the CU slots).  nblk0 = all blocks when there is only one map.
+__global__ void __launch_bounds__(ATT_THREADS) window_attention_f32_kernel(const WindowAttnParams pa, const WindowAttnParams pb, const int nblk0) {
+    const bool second = (int)blockIdx.x >= nblk0;
+    const WindowAttnParams& p = second ? pb : pa;
     __shared__ __attribute__((aligned(16))) float Ks[NTOK * KV_LD];
     __shared__ __attribute__((aligned(16))) float Vs[NTOK * KV_LD];
     __shared__ int src_s[NTOK];   // source token offset (pixel index) or -1 for a pad token
@@ -42,7 +47,7 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_f32_kernel(const
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int head = blockIdx.y;
     const int nWw = p.Wp / WS, nW = (p.Hp / WS) * nWw;
-    const int bw = blockIdx.x;
+    const int bw = second ? (int)blockIdx.x - nblk0 : (int)blockIdx.x;
     const int b = bw / nW, w = bw - b * nW;      // window batch index is b*nW + w (swin.rs:456-458)
     const int wr = w / nWw, wc = w - wr * nWw;
     const int C = p.C, C3 = 3 * C;
@@ -175,7 +180,9 @@ constexpr int VT_LD = 148;
 __device__ __forceinline__ int kswz(int key) { return (0x78 >> (2 * ((key >> 2) & 3))) & 3; }
 
 template <int NP>
-__global__ void __launch_bounds__(ATT_THREADS) window_attention_split_kernel(const WindowAttnParams p) {
+__global__ void __launch_bounds__(ATT_THREADS) window_attention_split_kernel(const WindowAttnParams pa, const WindowAttnParams pb, const int nblk0) {
+    const bool second = (int)blockIdx.x >= nblk0;
+    const WindowAttnParams& p = second ? pb : pa;
     __shared__ __attribute__((aligned(16))) __bf16 Kp[NP * NTOK * HD];
     __shared__ __attribute__((aligned(16))) __bf16 Vt[NP * HD * VT_LD];
     __shared__ float tab_s[(2 * WS - 1) * (2 * WS - 1)];
@@ -185,7 +192,7 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_split_kernel(con
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int head = blockIdx.y;
     const int nWw = p.Wp / WS, nW = (p.Hp / WS) * nWw;
-    const int bw = blockIdx.x;
+    const int bw = second ? (int)blockIdx.x - nblk0 : (int)blockIdx.x;
     const int b = bw / nW, w = bw - b * nW;
     const int wr = w / nWw, wc = w - wr * nWw;
     const int C = p.C, C3 = 3 * C;
@@ -363,15 +370,26 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_split_kernel(con
     }
 }
 
-hipError_t launch_window_attention(const WindowAttnParams& p, hipStream_t s) {
+static hipError_t check_attention(const WindowAttnParams& p) {
     if (p.C != p.heads * HD || p.Hp % WS || p.Wp % WS || p.Hp < p.H || p.Wp < p.W) return hipErrorInvalidValue;
     if (!(p.shift == 0 || p.shift == WS / 2)) return hipErrorInvalidValue;
-    const int nW = (p.Hp / WS) * (p.Wp / WS);
-    dim3 grid(p.B * nW, p.heads), block(ATT_THREADS);
-    if (p.planes == 2) hipLaunchKernelGGL(window_attention_split_kernel<2>, grid, block, 0, s, p);
-    else if (p.planes == 1) hipLaunchKernelGGL(window_attention_split_kernel<1>, grid, block, 0, s, p);
-    else hipLaunchKernelGGL(window_attention_f32_kernel, grid, block, 0, s, p);
+    return hipSuccess;
+}
+hipError_t launch_window_attention2(const WindowAttnParams& p, const WindowAttnParams* p2, hipStream_t s) {
+    if (check_attention(p) != hipSuccess) return hipErrorInvalidValue;
+    const int n0 = p.B * (p.Hp / WS) * (p.Wp / WS);
+    int n1 = 0;
+    if (p2) {
+        if (check_attention(*p2) != hipSuccess || p2->C != p.C || p2->heads != p.heads || p2->planes != p.planes) return hipErrorInvalidValue;
+        n1 = p2->B * (p2->Hp / WS) * (p2->Wp / WS);
+    }
+    const WindowAttnParams& q = p2 ? *p2 : p;
+    dim3 grid(n0 + n1, p.heads), block(ATT_THREADS);
+    if (p.planes == 2) hipLaunchKernelGGL(window_attention_split_kernel<2>, grid, block, 0, s, p, q, n0);
+    else if (p.planes == 1) hipLaunchKernelGGL(window_attention_split_kernel<1>, grid, block, 0, s, p, q, n0);
+    else hipLaunchKernelGGL(window_attention_f32_kernel, grid, block, 0, s, p, q, n0);
     return hipGetLastError();
 }
+hipError_t launch_window_attention(const WindowAttnParams& p, hipStream_t s) { return launch_window_attention2(p, nullptr, s); }
 
 }  // namespace brn
