@@ -59,7 +59,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // marches down M the GN weight panels of the group stay in its 4 MiB L2 and every A panel is fetched once per group
 // (the split-bf16 kernels are bound by L2-miss traffic, not by the matrix pipe).
 __device__ __forceinline__ void tile_coords(int tile, int tilesM, int tilesN, int& tm, int& tn) {
-    constexpr int GN = 4;
+    constexpr int GN = 8;
     const int per_group = tilesM * GN;
     const int g = tile / per_group, r = tile - g * per_group;
     const int gw = min(GN, tilesN - g * GN);
