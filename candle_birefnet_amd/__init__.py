@@ -8,3 +8,4 @@ from .config import BiRefNetConfig, DecoderConfig, SwinConfig  # noqa: F401
 from .weights import VarBuilder, birefnet_weight_spec, swin_weight_spec, synth_input, synth_weights  # noqa: F401
 from .birefnet import BiRefNet, DeformableConv2d, SwinTransformer  # noqa: F401
 from . import ops  # noqa: F401
+from . import imageproc  # noqa: F401

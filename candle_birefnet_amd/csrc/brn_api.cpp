@@ -398,6 +398,123 @@ brn_status brn_model_decoder_forward(brn_model* m, const float* x, const float* 
     });
 }
 
+// ---- image pre/post-processing (infer_image.rs:44-67, 84-110) -----------------------------------------------------------------
+extern "C++" {
+namespace {
+
+// One axis of image 0.25.9's resampler (imageops/sample.rs, horizontal_sample / vertical_sample): for every output index the
+// first input index, the tap count and the normalised weights, computed in f32 in the crate's order of operations.
+struct ResampleAxis {
+    int in_n = 0, out_n = 0, max_taps = 0;
+    std::vector<int> left, count;
+    std::vector<float> w;      // [out_n][max_taps]
+};
+enum { FILTER_TRIANGLE = 0, FILTER_LANCZOS3 = 1 };
+
+float sincf_image(float t) {
+    const float a = t * 3.14159265358979323846f;     // f32::consts::PI
+    return t == 0.0f ? 1.0f : sinf(a) / a;
+}
+float filter_kernel(int filter, float x) {
+    if (filter == FILTER_TRIANGLE) return fabsf(x) < 1.0f ? 1.0f - fabsf(x) : 0.0f;
+    return fabsf(x) < 3.0f ? sincf_image(x) * sincf_image(x / 3.0f) : 0.0f;
+}
+ResampleAxis make_axis(int in_n, int out_n, int filter) {
+    ResampleAxis ax;
+    ax.in_n = in_n; ax.out_n = out_n;
+    const float support = filter == FILTER_TRIANGLE ? 1.0f : 3.0f;
+    const float ratio = (float)in_n / (float)out_n;
+    const float sratio = ratio < 1.0f ? 1.0f : ratio;
+    const float src_support = support * sratio;
+    ax.left.resize(out_n); ax.count.resize(out_n);
+    std::vector<std::vector<float>> ws(out_n);
+    for (int o = 0; o < out_n; ++o) {
+        float inputx = ((float)o + 0.5f) * ratio;
+        long l = (long)floorf(inputx - src_support);
+        l = std::min<long>(std::max<long>(l, 0), (long)in_n - 1);
+        long r = (long)ceilf(inputx + src_support);
+        r = std::min<long>(std::max<long>(r, l + 1), (long)in_n);
+        inputx = inputx - 0.5f;
+        float sum = 0.0f;
+        for (long i = l; i < r; ++i) {
+            const float wv = filter_kernel(filter, ((float)i - inputx) / sratio);
+            ws[o].push_back(wv);
+            sum += wv;
+        }
+        for (float& v : ws[o]) v /= sum;
+        ax.left[o] = (int)l; ax.count[o] = (int)(r - l);
+        ax.max_taps = std::max(ax.max_taps, (int)(r - l));
+    }
+    ax.w.assign((size_t)out_n * ax.max_taps, 0.0f);
+    for (int o = 0; o < out_n; ++o) std::copy(ws[o].begin(), ws[o].end(), ax.w.begin() + (size_t)o * ax.max_taps);
+    return ax;
+}
+struct DevAxis { int* left; int* count; float* w; int max_taps; };
+DevAxis upload_axis(DeviceOwner& own, const ResampleAxis& ax) {
+    DevAxis d;
+    d.left = reinterpret_cast<int*>(own.upload(reinterpret_cast<const float*>(ax.left.data()), ax.left.size()));
+    d.count = reinterpret_cast<int*>(own.upload(reinterpret_cast<const float*>(ax.count.data()), ax.count.size()));
+    d.w = own.upload(ax.w);
+    d.max_taps = ax.max_taps;
+    return d;
+}
+unsigned char* dev_bytes(DeviceOwner& own, size_t n) {
+    std::vector<float> z((n + 3) / 4 + 4, 0.f);
+    return reinterpret_cast<unsigned char*>(own.upload(z));
+}
+
+}  // namespace
+}  // extern "C++"
+
+brn_status brn_preprocess_image(const unsigned char* pixels, int h, int w, int channels, int S, float* x_nchw, brn_mem out_loc,
+                                int device, void* stream) {
+    return guarded([&] {
+        if (!pixels || !x_nchw) fail(BRN_ERR_INVALID_ARG, "null argument");
+        if (h < 1 || w < 1 || S < 1 || !(channels == 3 || channels == 4))
+            fail(BRN_ERR_INVALID_ARG, "preprocess: %dx%d image with %d channels to %d: need RGB8 or RGBA8 and positive sizes", h, w, channels, S);
+        ensure_device(device);
+        hipStream_t s = (hipStream_t)stream;
+        DeviceOwner own;
+        Staging so(stream, out_loc);
+        float* dout = so.out(x_nchw, (size_t)3 * S * S);
+        const ResampleAxis ay = make_axis(h, S, FILTER_TRIANGLE), ax = make_axis(w, S, FILTER_TRIANGLE);   // resize_exact(S, S, Triangle)
+        const DevAxis dy = upload_axis(own, ay), dx = upload_axis(own, ax);
+        unsigned char* din = dev_bytes(own, (size_t)h * w * channels);
+        BRN_HIP(hipMemcpyAsync(din, pixels, (size_t)h * w * channels, hipMemcpyHostToDevice, s));
+        std::vector<float> z((size_t)S * w * channels, 0.f);
+        float* tmp = own.upload(z);                                    // the crate's intermediate Rgba32FImage (vertical pass first)
+        const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};    // infer_image.rs:53-54
+        BRN_HIP(launch_resample_v_u8(din, h, w, channels, S, dy.left, dy.count, dy.w, dy.max_taps, tmp, s));
+        BRN_HIP(launch_resample_h(tmp, S, w, channels, S, dx.left, dx.count, dx.w, dx.max_taps, nullptr, dout, mean, stdv, s));
+        so.finish();
+        BRN_HIP(hipStreamSynchronize(s));                               // `own` frees the temporaries when this scope ends
+    });
+}
+
+brn_status brn_postprocess_mask(const float* logits, int S, brn_mem in_loc, int apply_sigmoid, int out_h, int out_w,
+                                unsigned char* mask, int device, void* stream) {
+    return guarded([&] {
+        if (!logits || !mask) fail(BRN_ERR_INVALID_ARG, "null argument");
+        if (S < 1 || out_h < 1 || out_w < 1) fail(BRN_ERR_INVALID_ARG, "postprocess: sizes must be positive");
+        ensure_device(device);
+        hipStream_t s = (hipStream_t)stream;
+        DeviceOwner own;
+        Staging si(stream, in_loc);
+        const float* dl = si.in(logits, (size_t)S * S);
+        unsigned char* m8 = dev_bytes(own, (size_t)S * S);
+        BRN_HIP(launch_mask_u8(dl, (long)S * S, apply_sigmoid, m8, s));                       // infer_image.rs:84-99
+        const ResampleAxis ay = make_axis(S, out_h, FILTER_LANCZOS3), ax = make_axis(S, out_w, FILTER_LANCZOS3);   // :103-108
+        const DevAxis dy = upload_axis(own, ay), dx = upload_axis(own, ax);
+        std::vector<float> z((size_t)out_h * S, 0.f);
+        float* tmp = own.upload(z);
+        unsigned char* dout = dev_bytes(own, (size_t)out_h * out_w);
+        BRN_HIP(launch_resample_v_u8(m8, S, S, 1, out_h, dy.left, dy.count, dy.w, dy.max_taps, tmp, s));
+        BRN_HIP(launch_resample_h(tmp, out_h, S, 1, out_w, dx.left, dx.count, dx.w, dx.max_taps, dout, nullptr, nullptr, nullptr, s));
+        BRN_HIP(hipMemcpyAsync(mask, dout, (size_t)out_h * out_w, hipMemcpyDeviceToHost, s));
+        BRN_HIP(hipStreamSynchronize(s));
+    });
+}
+
 // ---- stand-alone SwinTransformer -----------------------------------------------------------------------------------------
 brn_status brn_swin_create(const brn_config* cfg, const brn_named_tensor* weights, size_t n, const char* prefix, int device,
                            brn_swin** out) {

@@ -115,6 +115,13 @@ hipError_t launch_conv3x3_to1(const float* x, int B, int H, int W, int C, int ld
                               float* y, hipStream_t s);
 // t = stencil5x5(x): the composed ipt_blk1 head on the NCHW image [B,3,H,W]; k = [9 border cases][5][5][3], bias = [9]
 hipError_t launch_head_stencil5x5(const float* img, int B, int H, int W, const float* k, const float* bias, float* y, hipStream_t s);
+// ---- image pre/post-processing (kernels/imageproc.hip; infer_image.rs:44-67,84-110) ----
+hipError_t launch_resample_v_u8(const unsigned char* in, int h, int w, int C, int nh, const int* left, const int* count,
+                                const float* wts, int max_taps, float* out, hipStream_t s);
+// out_f32 != null: channels 0..2 as ((v/255) - mean[c]) / std[c] into NCHW [3][nh][nw]; else u8 [nh][nw][C]
+hipError_t launch_resample_h(const float* in, int nh, int w, int C, int nw, const int* left, const int* count, const float* wts,
+                             int max_taps, unsigned char* out_u8, float* out_f32, const float* mean, const float* stdv, hipStream_t s);
+hipError_t launch_mask_u8(const float* logits, long n, int apply_sigmoid, unsigned char* out, hipStream_t s);
 // y = sigmoid(x)
 hipError_t launch_sigmoid(const float* x, size_t n, float* y, hipStream_t s);
 // modulator epilogue for deformable mode: columns [c0,c1) of rows get 2/(1+exp(-x))   (aspp.rs:173-174)

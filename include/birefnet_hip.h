@@ -208,6 +208,20 @@ brn_status brn_deform_conv2d_forward(const float* x, int B, int C, int H, int W,
                                      const float* w, const float* bias, int O, int k, int stride, int pad,
                                      int mode, float* y, brn_mem loc, int device_ordinal, void* stream);
 
+/* ---- image pre/post-processing: the steps either side of forward_logits in examples/infer_image.rs ------ */
+/* infer_image.rs:44-67.  `img.resize_exact(S, S, FilterType::Triangle)` -> `to_rgb8()` -> (v/255 - mean) / std with the
+ * ImageNet constants of :53-54 -> x [3,S,S] fp32 (NCHW, one image).  pixels: host, interleaved RGB8 or RGBA8 (channels 3|4;
+ * alpha is resampled like the crate does and then dropped by to_rgb8), row-major [h][w][channels].  The resampler restates
+ * image 0.25.9 (Cargo.lock:1102; imageops/sample.rs: vertical pass into f32, horizontal pass with clamp + round-to-nearest
+ * into u8, per-output weight tables normalised by their sum) — that crate is not vendored in the reference tree. */
+brn_status brn_preprocess_image(const unsigned char* pixels, int h, int w, int channels, int S,
+                                float* x_nchw_out, brn_mem out_loc, int device_ordinal, void* stream);
+/* infer_image.rs:84-110.  logits [S,S] -> sigmoid (apply_sigmoid != 0; pass 0 for brn_forward's output) ->
+ * `(v * 255.0).clamp(0.0, 255.0) as u8` -> `imageops::resize(&mask, out_w, out_h, FilterType::Lanczos3)` -> mask
+ * [out_h][out_w] u8 on the host. */
+brn_status brn_postprocess_mask(const float* logits, int S, brn_mem in_loc, int apply_sigmoid, int out_h, int out_w,
+                                unsigned char* mask_out, int device_ordinal, void* stream);
+
 /* ---- diagnostics ---------------------------------------------------------------------------------------- */
 /* Times `iters` launches of the dense gemm_f32 kernel on random device data (M x K times N x K^T).  tile_cfg: -1 = the
  * library's own plan, 0 = 128x128, 1 = 128x64, 2 = 64x64 block tile; splitk only with tile_cfg >= 0; add 1000*planes
