@@ -58,8 +58,14 @@ static void fill_epilogue(GemmParams& p, const GemmW& w) {
 }
 
 void run_gemm(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* C, int ldc, int c_coff, const float* R, int ldr,
-              int r_coff, const float* bbias, int bbias_rows) {
-    const GemmPlan pl = plan_gemm(M, w.N, w.K, w.wp ? w.planes : 0);
+              int r_coff, const float* bbias, int bbias_rows, int a_planes, int c_planes) {
+    GemmPlan pl = plan_gemm(M, w.N, w.K, w.wp ? w.planes : 0);
+    if (a_planes || c_planes) {
+        // P2 operands exist only on the warp-specialised 2-plane kernel; a P2 output cannot go through the split-K reduce pass
+        if (!(w.wp && w.planes == 2)) fail(BRN_ERR_INVALID_ARG, "P2 activation layout outside the f32_split2 mode");
+        pl.cfg = 0;
+        if (c_planes) { pl.splitk = 1; pl.ws_floats = 0; }
+    }
     const size_t mk = c.arena->mark();
     float* ws = pl.ws_floats ? c.arena->alloc(pl.ws_floats) : nullptr;
     c.arena->release(mk);          // scratch is dead as soon as the reduce pass has been enqueued (in-order stream)
@@ -69,6 +75,7 @@ void run_gemm(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* C, 
     fill_epilogue(p, w);
     p.bbias = bbias; p.bbias_rows = bbias_rows > 0 ? bbias_rows : 1;
     p.R = R; p.ldr = ldr; p.r_coff = r_coff; p.ldc = ldc; p.c_coff = c_coff;
+    p.a_planes = a_planes; p.c_planes = c_planes;
     const double flop = 2.0 * M * (double)w.N * w.K;
     const double bytes = 4.0 * ((double)M * w.K + (double)w.N * w.K + (double)M * w.N * (R ? 2 : 1));
     Bracket b(c, FAM_GEMM_DENSE, flop, bytes, M, w.N, w.K);
@@ -131,11 +138,11 @@ void run_conv_nchw(Ctx& c, const GemmW& w, const float* x, int B, int Hin, int W
     BRN_LAUNCH(launch_gemm(p, pl, ws, c.stream));
 }
 
-void run_layernorm(Ctx& c, const LNW& ln, const float* x, int rows, int ldx, float* y, int ldy, int y_coff) {
+void run_layernorm(Ctx& c, const LNW& ln, const float* x, int rows, int ldx, float* y, int ldy, int y_coff, int y_planes) {
     if (c.dry) return;
     LayerNormParams p{};
     p.x = x; p.y = y; p.rows = rows; p.C = ln.C; p.gamma = ln.g; p.beta = ln.b; p.eps = 1e-5f;
-    p.ldx = ldx; p.ldy = ldy; p.y_coff = y_coff; p.mode = 0;
+    p.ldx = ldx; p.ldy = ldy; p.y_coff = y_coff; p.mode = 0; p.y_planes = y_planes;
     Bracket b(c, FAM_LAYERNORM, 0.0, 8.0 * rows * (double)ln.C);
     BRN_LAUNCH(launch_layernorm(p, c.stream));
 }
@@ -159,13 +166,13 @@ void swin_stage_dims(int H, int W, int patch, int hs[4], int ws[4]) {
 // The attention half of a block for `nin` token sets that share the weights (the full- and half-scale backbone passes
 // of birefnet.rs:416,426 are run as ONE pass over concatenated token rows: every per-token op sees M = M_full + M_half).
 static void swin_attention_multi(Ctx& c, const SwinBlockW& blk, const float* xn, int B, int nin, const int* hs, const int* wsz, int C,
-                                 int shift, float* y, const float* residual) {
+                                 int shift, float* y, const float* residual, int p2 = 0) {
     const size_t mk = c.arena->mark();
     int M = 0;
     for (int k = 0; k < nin; ++k) M += B * hs[k] * wsz[k];
     float* qkv = c.arena->alloc((size_t)M * 3 * C);
     float* att = c.arena->alloc((size_t)M * C);
-    run_gemm(c, blk.qkv, xn, M, C, qkv, 3 * C, 0);                   // swin.rs:217 (pad rows are synthesised by the kernel)
+    run_gemm(c, blk.qkv, xn, M, C, qkv, 3 * C, 0, nullptr, 0, 0, nullptr, 0, p2, 0);   // swin.rs:217 (pad rows are synthesised by the kernel)
     if (!c.dry) {
         // one launch for all maps of the pass (full + half scale): fewer ramps and tails than one launch per geometry
         WindowAttnParams ps[2]{};
@@ -178,13 +185,14 @@ static void swin_attention_multi(Ctx& c, const SwinBlockW& blk, const float* xn,
             p.Hp = roundup(hs[k], 12); p.Wp = roundup(wsz[k], 12);   // swin.rs:359-360
             p.shift = shift; p.scale = 1.0f / sqrtf(32.0f);          // head_dim^-0.5 (swin.rs:134)
             p.planes = (blk.qkv.planes == 2 || blk.qkv.planes == 1) ? blk.qkv.planes : 0;
+            p.out_planes = p2;
             nwin += (double)B * (p.Hp / 12) * (p.Wp / 12) * blk.heads;
             off += (size_t)B * hs[k] * wsz[k];
         }
         Bracket b(c, FAM_ATTENTION, nwin * 2.0 * 2.0 * 144 * 144 * 32, 4.0 * ((double)M * 4 * C), M, C, shift);
         BRN_LAUNCH(launch_window_attention2(ps[0], nin > 1 ? &ps[1] : nullptr, c.stream));
     }
-    run_gemm(c, blk.proj, att, M, C, y, C, 0, residual, C, 0);      // swin.rs:310 (+ shortcut, swin.rs:406)
+    run_gemm(c, blk.proj, att, M, C, y, C, 0, residual, C, 0, nullptr, 0, p2, 0);      // swin.rs:310 (+ shortcut, swin.rs:406)
     c.arena->release(mk);
 }
 
@@ -229,11 +237,14 @@ void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int 
         for (size_t j = 0; j < st.blocks.size(); ++j) {
             const SwinBlockW& bk = st.blocks[j];
             const int shift = (j % 2 == 0) ? 0 : w.window / 2;                       // swin.rs:552
-            run_layernorm(c, bk.norm1, x, M, C, xn, C, 0);                            // swin.rs:355
-            swin_attention_multi(c, bk, xn, B, nin, hh, ww, C, shift, x, x);          // x = shortcut + attn (swin.rs:406)
-            run_layernorm(c, bk.norm2, x, M, C, xn, C, 0);                            // swin.rs:407
-            run_gemm(c, bk.fc1, xn, M, C, hid, hidden, 0);                            // fc1 + gelu_erf (swin.rs:104-105)
-            run_gemm(c, bk.fc2, hid, M, hidden, x, C, 0, x, C, 0);                    // x + fc2(...) (swin.rs:106,407)
+            // mode f32_split2: every GEMM input of the block is written by its producer in the P2 layout (the two bf16 planes
+            // the GEMM would split out while staging), so the GEMMs' staging waves only copy
+            const int p2 = (bk.qkv.wp && bk.qkv.planes == 2 && bk.fc1.wp && bk.fc2.wp && bk.proj.wp && C % 32 == 0 && hidden % 32 == 0) ? 2 : 0;
+            run_layernorm(c, bk.norm1, x, M, C, xn, C, 0, p2);                        // swin.rs:355
+            swin_attention_multi(c, bk, xn, B, nin, hh, ww, C, shift, x, x, p2);      // x = shortcut + attn (swin.rs:406)
+            run_layernorm(c, bk.norm2, x, M, C, xn, C, 0, p2);                        // swin.rs:407
+            run_gemm(c, bk.fc1, xn, M, C, hid, hidden, 0, nullptr, 0, 0, nullptr, 0, p2, p2);   // fc1 + gelu_erf (swin.rs:104-105)
+            run_gemm(c, bk.fc2, hid, M, hidden, x, C, 0, x, C, 0, nullptr, 0, p2, 0);  // x + fc2(...) (swin.rs:106,407)
         }
         // stage output = norm_i(x_out), pre-downsample (swin.rs:591,784-789); written into its consumer's window
         size_t off = 0, off2 = 0;
@@ -250,6 +261,7 @@ void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int 
                     LayerNormParams p{};
                     p.x = x + off * C; p.y = pm + off2 * 4 * C; p.rows = M2; p.C = 4 * C; p.gamma = st.down_norm.g; p.beta = st.down_norm.b;
                     p.eps = 1e-5f; p.ldy = 4 * C; p.y_coff = 0; p.mode = 1; p.H = hh[k]; p.W = ww[k]; p.Cin = C;
+                    p.y_planes = (st.reduction.wp && st.reduction.planes == 2 && (4 * C) % 32 == 0) ? 2 : 0;   // P2 for the reduction GEMM
                     Bracket b(c, FAM_LAYERNORM, 0.0, 8.0 * M2 * 4.0 * C);
                     BRN_LAUNCH(launch_layernorm(p, c.stream));
                 }
@@ -257,7 +269,10 @@ void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int 
             }
             off += rows(k, i);
         }
-        if (st.has_down) run_gemm(c, st.reduction, pm, total(i + 1), 4 * C, xnext, 2 * C, 0);
+        if (st.has_down) {
+            const int p2 = (st.reduction.wp && st.reduction.planes == 2 && (4 * C) % 32 == 0) ? 2 : 0;
+            run_gemm(c, st.reduction, pm, total(i + 1), 4 * C, xnext, 2 * C, 0, nullptr, 0, 0, nullptr, 0, p2, 0);
+        }
         c.arena->release(mk);
         x = xnext;
     }

@@ -188,10 +188,11 @@ void fold_bn(DeviceOwner& own, GemmW& g, const float* conv_bias_host, const floa
 
 // ---- graph pieces ------------------------------------------------------------------------------------------------
 void run_gemm(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* C, int ldc, int c_coff,
-              const float* R = nullptr, int ldr = 0, int r_coff = 0, const float* bbias = nullptr, int bbias_rows = 1);
+              const float* R = nullptr, int ldr = 0, int r_coff = 0, const float* bbias = nullptr, int bbias_rows = 1,
+              int a_planes = 0, int c_planes = 0 /* 2: operand in the P2 layout (kernels/split_planes.h) */);
 void run_conv(Ctx& c, const GemmW& w, const Map& in, const Map& out, const float* om = nullptr, int om_ld = 0, int om_mask_off = 0);
 void run_conv_nchw(Ctx& c, const GemmW& w, const float* x_nchw, int B, int Hin, int Win, const Map& out);
-void run_layernorm(Ctx& c, const LNW& ln, const float* x, int rows, int ldx, float* y, int ldy, int y_coff);
+void run_layernorm(Ctx& c, const LNW& ln, const float* x, int rows, int ldx, float* y, int ldy, int y_coff, int y_planes = 0);
 void run_resize(Ctx& c, const Map& in, const Map& out);
 
 // SwinTransformer::forward (swin.rs:768-797): outs[i] are destination windows (stage outputs after norm_i)

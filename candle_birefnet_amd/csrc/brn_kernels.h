@@ -41,6 +41,7 @@ struct GemmParams {
     const void* Wp; int planes; int wp_rows;
     // split-K (filled by launch_gemm from the plan): slices write raw partials to part[slice][M][N]
     int splitk; float* part;
+    int a_planes, c_planes;   // 2: A is read / C is written in the P2 layout (kernels/split_planes.h); split-bf16 dense ws kernel only
     unsigned long long* trace;   // diagnostics only: per-workgroup cycle stamps (gemm_split_ws_kernel), null in production
     int abl;   // diagnostics only (brn_gemm_microbench): 1 = no global loads in the K loop, 2 = no LDS staging, 4 = no fragment reads / MFMA
 };
@@ -64,6 +65,7 @@ struct LayerNormParams {
     // mode 1: PatchMerging gather (swin.rs:505-522): row (b,i,j) of the merged map gathers the four tokens
     // (2i,2j),(2i+1,2j),(2i,2j+1),(2i+1,2j+1) of x [B,H,W,Cin], zero outside (odd H/W padding), C == 4*Cin
     int mode; int H, W, Cin;
+    int y_planes;         // 2: write y in the P2 layout (kernels/split_planes.h) for a split-bf16 GEMM; 0: fp32
 };
 hipError_t launch_layernorm(const LayerNormParams& p, hipStream_t s);
 
@@ -77,6 +79,7 @@ struct WindowAttnParams {
     int shift;            // 0 or 6
     float scale;          // head_dim^-0.5
     int planes;           // 0: fp32 MFMA kernel (modes f32, f32_split3); 2 / 1: bf16-split kernel (f32_split2 / bf16_operands)
+    int out_planes;       // 2: write `out` in the P2 layout (kernels/split_planes.h) for the proj GEMM; 0: fp32
 };
 hipError_t launch_window_attention(const WindowAttnParams& p, hipStream_t s);
 // two maps of the same stage in one launch (p2 may be null)

@@ -16,6 +16,7 @@
 // 36 floats: conflict-free for the b128 lane groups).  Global->LDS goes through registers (one float4 per
 // thread per 32 rows) with the next tile's loads in flight during the current tile's 64-cycle MFMAs.
 #include "../brn_kernels.h"
+#include "split_planes.h"
 
 namespace brn {
 
@@ -367,39 +368,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_f32_kernel(const GemmParams 
 // NP = 2 keeps hh, hm, mh (~2^-16 relative); NP = 1 is plain bf16 x bf16 -> fp32 (the bf16 throughput mode).
 // LDS: per plane [rows][40 bf16] (80-byte rows: conflict-free for the ds_read_b128 lane groups).
 // =====================================================================================================================
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int SLD = 40;   // bf16 elements per LDS row
-
-// Error-free split of four fp32 values (times a 0/1 row mask) into NP bf16 planes: plane 0 = RNE bf16(x), plane p+1 = RNE
-// bf16 of what is left.  Written with one-instruction asm pieces on purpose: left to the compiler, the multiplies and
-// subtractions become packed-fp32 instructions (v_pk_mul_f32 / v_pk_fma_f32 with op_sel), and with those this kernel's
-// producer waves stored wrong A rows a few times per 10^5 K tiles while MFMA waves shared their SIMD (always the last 16
-// lanes, always the op_sel'd operand; tools/race_ints.py is the reproducer).  Plain VALU forms are also cheaper beside MFMAs.
-__device__ __forceinline__ float valu_mul(float a, float b) { float r; asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float valu_sub(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ unsigned valu_cvt_pk_bf16(float a, float b) { unsigned r; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-template <int NP>
-__device__ __forceinline__ void split4(const f32x4 v, const float mask, bf16x4 (&out)[NP]) {
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    float r[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) r[e] = valu_mul(v[e], mask);
-#pragma unroll
-    for (int pl = 0; pl < NP; ++pl) {
-        u32x2 h;
-        h[0] = valu_cvt_pk_bf16(r[0], r[1]);
-        h[1] = valu_cvt_pk_bf16(r[2], r[3]);
-        out[pl] = __builtin_bit_cast(bf16x4, h);
-        if (pl + 1 < NP) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                r[2 * q] = valu_sub(r[2 * q], __builtin_bit_cast(float, h[q] << 16));
-                r[2 * q + 1] = valu_sub(r[2 * q + 1], __builtin_bit_cast(float, h[q] & 0xffff0000u));
-            }
-        }
-    }
-}
 
 template <int BM, int BN, int WM, int WN, int MODE, int NP>
 __global__ void __launch_bounds__(WM* WN * 64) gemm_split_kernel(const GemmParams p) {
@@ -622,7 +591,9 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, const fl
         if (p.scale) v = v * sc + sh;
         v = act4(v, p.act);
         float* dst = p.C + (long)m * p.ldc + p.c_coff + n;
-        if (vec) {
+        if (p.c_planes == 2) {              // the next GEMM reads the P2 layout (launch_gemm checked N, ldc, c_coff % 32 == 0, no R)
+            store_planes2(p.C + (long)m * p.ldc, p.c_coff + n, v);
+        } else if (vec) {
             if (p.R) v = v + *reinterpret_cast<const f32x4*>(p.R + (long)m * p.ldr + p.r_coff + n);
             *reinterpret_cast<f32x4*>(dst) = v;
         } else {
@@ -647,10 +618,12 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, const fl
 // registers: at bf16 MFMA rates an exposed LDS read (~250 cycles) per 32-deep K tile (768 MFMA cycles) was a third of the
 // loop (measured by ablation: staging and MFMA phases added up, then the fragment-read stall did).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int MODE, int NP, int KS, bool DIAG>   // DIAG: ablation switches + per-K-tile cycle stamps (brn_gemm_microbench only; costs registers)
+template <int MODE, int NP, int KS, bool DIAG, bool APL>   // APL: A arrives in the P2 layout (its producer already split it): the staging waves only copy
+// DIAG: ablation switches + per-K-tile cycle stamps (brn_gemm_microbench only; costs registers)
 // KS = k elements per LDS stage (32, or 16 to halve the stage when 3 planes must fit twice per CU)
 __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) {
     constexpr int BM = 128, BN = 128, WTM = 64, WTN = 64, TM = 2, TN = 2;
+    static_assert(!APL || (NP == 2 && MODE == GEMM_DENSE), "the P2 input layout is the 2-plane split of a dense A");
     constexpr int SLD = KS + 8;                     // bf16 per LDS row (16-byte pad: conflict-free b128 fragment reads)
     constexpr int KSTEPS = KS / 16;                 // MFMA k-steps per stage
     constexpr int NBUF = 2;                         // 2 x NP x 20 KB: two workgroups per CU at NP <= 2 (a 3-deep ring was slower: 1 WG/CU exposes each tile's prologue + epilogue)
@@ -729,7 +702,12 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
 #pragma unroll
                 for (int i = 0; i < PB; ++i)
                     qb[pl][i] = *reinterpret_cast<const bf16x8*>(wsrc + (long)i * WRPP * wrow_stride + (long)(kt0 + t) * (NP * 32) + pl * 32);
-            if (MODE == GEMM_DENSE) {
+            if (APL) {
+                // row m's K tile = 128 bytes at float offset k0: 8 x 16-byte chunks, kq 0-3 = hi plane, kq 4-7 = lo plane
+#pragma unroll
+                for (int i = 0; i < PA; ++i)
+                    qa[i] = load4_masked(p.A + (a_ok[i] ? a_base[i] : 0) + k0 + kq * 4, a_ok[i], qm[i]);
+            } else if (MODE == GEMM_DENSE) {
 #pragma unroll
                 for (int i = 0; i < PA; ++i)
                     {
@@ -751,6 +729,17 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
         auto lds_store = [&](int t, const f32x4 (&qa)[PA], const bf16x8 (&qb)[NP][PB], const float (&qm)[PA]) {
             __bf16* As = smem + (t % NBUF) * BUF;
             __bf16* Bs = As + NP * BM * SLD;
+            if (APL) {
+                // 16 bytes = 8 bf16 of plane kq >> 2 at k = 8 (kq & 3): one ds_write_b128, no arithmetic (rows beyond M were
+                // loaded from row 0 and are zeroed by an integer AND with the row's 0 / ~0 mask)
+#pragma unroll
+                for (int i = 0; i < PA; ++i) {
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    const unsigned keep = qm[i] != 0.f ? 0xffffffffu : 0u;
+                    const u32x4 bits = __builtin_bit_cast(u32x4, qa[i]) & keep;
+                    *reinterpret_cast<u32x4*>(As + ((kq >> 2) * BM + lrow + i * RPP) * SLD + (kq & 3) * 8) = bits;
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < PA; ++i) {
                 bf16x4 sp[NP];
@@ -758,6 +747,7 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl)
                     *reinterpret_cast<bf16x4*>(As + (pl * BM + lrow + i * RPP) * SLD + kq * 4) = sp[pl];
+            }
             }
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
@@ -880,9 +870,17 @@ static hipError_t launch_split_ws(const GemmParams& p, hipStream_t s) {
     const int tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128) * p.splitk;
     dim3 grid(tiles), block(512);
     constexpr int KS = 32;                  // (16-deep stages were tried for 3 planes: registers, not LDS, cap residency; slower)
-    if (p.mode == GEMM_DENSE && (p.abl || p.trace)) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, NP, KS, true>), grid, block, 0, s, p);
-    else if (p.mode == GEMM_DENSE) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, NP, KS, false>), grid, block, 0, s, p);
-    else if (p.mode == GEMM_CONV_NHWC) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_CONV_NHWC, NP, KS, false>), grid, block, 0, s, p);
+    if (p.a_planes) {
+        if constexpr (NP == 2) {
+            if (p.mode != GEMM_DENSE) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, 2, KS, false, true>), grid, block, 0, s, p);
+            return hipGetLastError();
+        }
+        return hipErrorInvalidValue;
+    }
+    if (p.mode == GEMM_DENSE && (p.abl || p.trace)) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, NP, KS, true, false>), grid, block, 0, s, p);
+    else if (p.mode == GEMM_DENSE) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, NP, KS, false, false>), grid, block, 0, s, p);
+    else if (p.mode == GEMM_CONV_NHWC) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_CONV_NHWC, NP, KS, false, false>), grid, block, 0, s, p);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -1207,6 +1205,12 @@ hipError_t launch_gemm(const GemmParams& p_in, const GemmPlan& pl, float* ws, hi
     p.splitk = pl.splitk < 1 ? 1 : pl.splitk;
     p.part = ws;
     if (p.splitk > 1 && !ws) return hipErrorInvalidValue;
+    if (p.a_planes || p.c_planes) {         // P2 layouts: 2-plane split mode, dense, on the warp-specialised kernel only
+        const bool ws_cfg = pl.cfg == 6 || pl.cfg == 0 || pl.cfg == 3 || pl.cfg == 4 || pl.cfg == 5;
+        if (p.planes != 2 || !p.Wp || p.mode != GEMM_DENSE || !ws_cfg) return hipErrorInvalidValue;
+        if (p.a_planes && (p.a_planes != 2 || p.lda % 32 || p.a_coff)) return hipErrorInvalidValue;
+        if (p.c_planes && (p.c_planes != 2 || p.splitk > 1 || p.R || p.N % 32 || p.ldc % 32 || p.c_coff % 32)) return hipErrorInvalidValue;
+    }
     hipError_t e;
     if (p.planes > 0 && p.Wp && (p.mode == GEMM_DENSE || p.mode == GEMM_CONV_NHWC)) {
         // split-bf16 path: tile choice by the same plan (64x64 / 128x64 / 128x128 families); the 128x128 tile runs

@@ -1,0 +1,54 @@
+// split_planes.h — device helpers shared by the kernels that produce or consume bf16 operand planes.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace brn {
+
+typedef float f32x4_sp __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// Error-free split of four fp32 values (times a 0/1 row mask) into NP bf16 planes: plane 0 = RNE bf16(x), plane p+1 = RNE
+// bf16 of what is left.  Written with one-instruction asm pieces on purpose: left to the compiler, the multiplies and
+// subtractions become packed-fp32 instructions (v_pk_mul_f32 / v_pk_fma_f32 with op_sel), and with those this kernel's
+// producer waves stored wrong A rows a few times per 10^5 K tiles while MFMA waves shared their SIMD (always the last 16
+// lanes, always the op_sel'd operand; tools/race_ints.py is the reproducer).  Plain VALU forms are also cheaper beside MFMAs.
+__device__ __forceinline__ float valu_mul(float a, float b) { float r; asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float valu_sub(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ unsigned valu_cvt_pk_bf16(float a, float b) { unsigned r; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+template <int NP>
+__device__ __forceinline__ void split4(const f32x4_sp v, const float mask, bf16x4 (&out)[NP]) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    float r[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = valu_mul(v[e], mask);
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) {
+        u32x2 h;
+        h[0] = valu_cvt_pk_bf16(r[0], r[1]);
+        h[1] = valu_cvt_pk_bf16(r[2], r[3]);
+        out[pl] = __builtin_bit_cast(bf16x4, h);
+        if (pl + 1 < NP) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                r[2 * q] = valu_sub(r[2 * q], __builtin_bit_cast(float, h[q] << 16));
+                r[2 * q + 1] = valu_sub(r[2 * q + 1], __builtin_bit_cast(float, h[q] & 0xffff0000u));
+            }
+        }
+    }
+}
+
+
+// "P2" activation layout (mode f32_split2): an fp32 matrix [M][K], K % 32 == 0, stored by its PRODUCER as the two bf16 planes the
+// GEMM would otherwise split out while staging it.  Same bytes per row as fp32: K tile kt (32 elements) of a row occupies
+// bytes [128 kt, 128 kt + 64) = 32 hi values, [128 kt + 64, 128 kt + 128) = 32 lo values.  `row` points at the row's first
+// byte, `col` (a multiple of 4) is the logical column of v[0].
+__device__ __forceinline__ void store_planes2(float* row, int col, const f32x4_sp v) {
+    bf16x4 sp[2];
+    split4<2>(v, 1.0f, sp);
+    char* base = reinterpret_cast<char*>(row) + (col >> 5) * 128 + (col & 31) * 2;
+    *reinterpret_cast<bf16x4*>(base) = sp[0];
+    *reinterpret_cast<bf16x4*>(base + 64) = sp[1];
+}
+
+}  // namespace brn

@@ -21,6 +21,7 @@
 //                               4g..4g+3 of a 16-key tile; step r contracts key 4g + r), A = V^T read from LDS with
 //                               the same key permutation.  No transpose, no LDS round trip for P.
 #include "../brn_kernels.h"
+#include "split_planes.h"
 
 namespace brn {
 
@@ -363,9 +364,15 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_split_kernel(con
         }
         if (qsrc >= 0) {
             const float inv = 1.0f / sum;
-            float* op = p.out + (long)qsrc * C + head * HD + g * 4;
-            *reinterpret_cast<f32x4*>(op) = o0 * inv;
-            *reinterpret_cast<f32x4*>(op + 16) = o1 * inv;
+            if (p.out_planes == 2) {        // the proj GEMM reads the P2 layout: a head's 32 outputs are one K tile of the row
+                float* orow = p.out + (long)qsrc * C;
+                store_planes2(orow, head * HD + g * 4, o0 * inv);
+                store_planes2(orow, head * HD + 16 + g * 4, o1 * inv);
+            } else {
+                float* op = p.out + (long)qsrc * C + head * HD + g * 4;
+                *reinterpret_cast<f32x4*>(op) = o0 * inv;
+                *reinterpret_cast<f32x4*>(op + 16) = o1 * inv;
+            }
         }
     }
 }
@@ -380,9 +387,10 @@ hipError_t launch_window_attention2(const WindowAttnParams& p, const WindowAttnP
     const int n0 = p.B * (p.Hp / WS) * (p.Wp / WS);
     int n1 = 0;
     if (p2) {
-        if (check_attention(*p2) != hipSuccess || p2->C != p.C || p2->heads != p.heads || p2->planes != p.planes) return hipErrorInvalidValue;
+        if (check_attention(*p2) != hipSuccess || p2->C != p.C || p2->heads != p.heads || p2->planes != p.planes || p2->out_planes != p.out_planes) return hipErrorInvalidValue;
         n1 = p2->B * (p2->Hp / WS) * (p2->Wp / WS);
     }
+    if (p.out_planes && (p.out_planes != 2 || p.planes != 2)) return hipErrorInvalidValue;
     const WindowAttnParams& q = p2 ? *p2 : p;
     dim3 grid(n0 + n1, p.heads), block(ATT_THREADS);
     if (p.planes == 2) hipLaunchKernelGGL(window_attention_split_kernel<2>, grid, block, 0, s, p, q, n0);
