@@ -853,12 +853,31 @@ brn_status brn_gemm_microbench(int M, int N, int K, int tile_cfg, int splitk, in
         std::vector<float> hc((size_t)M * N, 0.f);
         float* dC = own.upload(hc);
         GemmPlan pl = plan_gemm(M, N, K, gw.wp ? gw.planes : 0);
+        bool a_p2 = false;
+        if (tile_cfg == 9) { tile_cfg = 0; a_p2 = true; }     // 2009: warp-specialised kernel fed an A that is already in the P2 layout
         if (tile_cfg >= 0) { pl.cfg = tile_cfg; pl.splitk = splitk > 1 ? splitk : 1; pl.ws_floats = pl.splitk > 1 ? (size_t)pl.splitk * M * N : 0; }
+        if (a_p2) {
+            if (planes != 2 || K % 32) fail(BRN_ERR_INVALID_ARG, "P2 input needs the 2-plane mode");
+            auto bf = [](float x) { uint32_t u; std::memcpy(&u, &x, 4); const uint32_t r = u + 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(r >> 16); };
+            auto fl = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; };
+            std::vector<float> p2(ha.size());
+            uint16_t* q = reinterpret_cast<uint16_t*>(p2.data());
+            for (int m = 0; m < M; ++m)
+                for (int k = 0; k < K; ++k) {
+                    const float x = ha[(size_t)m * K + k];
+                    const uint16_t h = bf(x), l = bf(x - fl(h));
+                    uint16_t* row = q + (size_t)m * K * 2;
+                    row[(k / 32) * 64 + (k % 32)] = h;
+                    row[(k / 32) * 64 + 32 + (k % 32)] = l;
+                }
+            BRN_HIP(hipMemcpy(dA, p2.data(), p2.size() * 4, hipMemcpyHostToDevice));
+        }
         float* ws = nullptr;
         if (pl.ws_floats) { std::vector<float> z(pl.ws_floats, 0.f); ws = own.upload(z); }
         GemmParams p{};
         p.A = dA; p.W = dW; p.C = dC; p.M = M; p.N = N; p.K = K; p.mode = GEMM_DENSE; p.lda = K; p.ldc = N; p.bbias_rows = 1;
         p.Wp = gw.wp; p.planes = gw.planes; p.wp_rows = gw.wp_rows;
+        p.a_planes = a_p2 ? 2 : 0;
         if (const char* ab = getenv("BRN_GEMM_ABLATE")) p.abl = atoi(ab);
         std::vector<float> hb((size_t)N, 0.1f);
         if (const char* ac = getenv("BRN_GEMM_ACT")) { p.act = atoi(ac); p.bias = own.upload(hb); }          // epilogue cost probes

@@ -873,7 +873,8 @@ static hipError_t launch_split_ws(const GemmParams& p, hipStream_t s) {
     if (p.a_planes) {
         if constexpr (NP == 2) {
             if (p.mode != GEMM_DENSE) return hipErrorInvalidValue;
-            hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, 2, KS, false, true>), grid, block, 0, s, p);
+            if (p.abl || p.trace) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, 2, KS, true, true>), grid, block, 0, s, p);
+            else hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, 2, KS, false, true>), grid, block, 0, s, p);
             return hipGetLastError();
         }
         return hipErrorInvalidValue;
