@@ -114,8 +114,7 @@ struct ASPPW {             // ASPPDeformable (aspp.rs:227-333)
 struct DecBlkW { GemmW conv_in; ASPPW aspp; GemmW conv_out; int cin = 0, cout = 0; };
 struct SimpleConvsW { GemmW conv1, conv_out; };
 struct DecoderW {
-    SimpleConvsW ipt[5];   // ipt_blk1..5 (ipt[0] = ipt_blk1: conv1 only, conv_out is composed into tail_w)
-    float* tail_w = nullptr; float tail_b = 0.f;   // [9][64]: conv_out1[192:240] o ipt_blk1.conv_out
+    SimpleConvsW ipt[5];   // ipt_blk2..5 at [1..4]; ipt_blk1 ([0]) is composed into head_k / head_b
     float* head_k = nullptr; float* head_b = nullptr;   // [3x3 border cases][5][5][3] + [9]: that stencil o ipt_blk1.conv1 (see brn_weights.cpp)
     DecBlkW dec[4];        // decoder_block4,3,2,1
     GemmW lat[3];          // lateral_block4,3,2

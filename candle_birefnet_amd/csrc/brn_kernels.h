@@ -113,9 +113,6 @@ hipError_t launch_pixel_dot(const float* x, int npix, int C, int ldx, int x_coff
 // out[b][oy][ox] = bilinear(q [B,h,w] -> H,W) + t[b][oy][ox] (+bias); optional sigmoid
 hipError_t launch_final_head(const float* q, int B, int h, int w, const float* t, float bias, int H, int W,
                              int apply_sigmoid, float* out, hipStream_t s);
-// 3x3 conv, pad 1, of a 64-channel channels-last map to one channel (composed ipt_blk1.conv_out o conv_out1 slice)
-hipError_t launch_conv3x3_to1(const float* x, int B, int H, int W, int C, int ldx, const float* w, float bias,
-                              float* y, hipStream_t s);
 // t = stencil5x5(x): the composed ipt_blk1 head on the NCHW image [B,3,H,W]; k = [9 border cases][5][5][3], bias = [9]
 hipError_t launch_head_stencil5x5(const float* img, int B, int H, int W, const float* k, const float* bias, float* y, hipStream_t s);
 // ---- image pre/post-processing (kernels/imageproc.hip; infer_image.rs:44-67,84-110) ----

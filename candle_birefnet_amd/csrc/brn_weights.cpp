@@ -349,13 +349,7 @@ void build_decoder_weights(const WeightTable& wt, const std::string& p, const br
             fail(BRN_ERR_INVALID_ARG, "ipt_blk%d expects %d channels but image2patches yields %d: only the Swin-L channel plan "
                  "[192,384,768,1536] with mul_scl_ipt is self-consistent in the reference (birefnet.rs:189-193,304-316)",
                  i + 1, ipt_in[i], patch_ch[i]);
-    // ipt_blk1: conv1 reads the NCHW image directly; conv_out (64->48) is composed with conv_out1's ipt slice below
-    {
-        const std::string ip = p + "ipt_blk1.";
-        const float* w = wt.get(ip + "conv1.weight", {64, 3, 3, 3})->data;
-        const float* b = wt.get(ip + "conv1.bias", {64})->data;
-        out.ipt[0].conv1 = make_conv_gather(own, w, b, 64, 3, 3, 3, 1, 1, 1);
-    }
+    // ipt_blk1 (conv1 3->64, conv_out 64->48, no activation) is composed with conv_out1's ipt slice into one stencil below
     for (int i = 1; i < 5; ++i) {
         const std::string ip = p + "ipt_blk" + std::to_string(i + 1) + ".";
         const int cin = ipt_in[i], cinp = roundup(cin, 32);
@@ -409,8 +403,6 @@ void build_decoder_weights(const WeightTable& wt, const std::string& p, const br
             }
         double tb = 0.0;
         for (int o = 0; o < ipt_out[0]; ++o) tb += (double)ow[dec_out[3] + o] * (double)b2[o];
-        out.tail_w = own.upload(tw);
-        out.tail_b = (float)tb;
         // One level further: ipt_blk1.conv1 (3x3, 3 -> 64, pad 1, bias b1) feeds that stencil with nothing in between
         // (SimpleConvs has no activation, decoder.rs:52), so t = stencil3x3(conv1(x)) is ONE 5x5, 3 -> 1 stencil on the image:
         //   t(p) = tb + sum_{d in D(p)} sum_ci tw[d][ci] * (b1[ci] + sum_e sum_c W1[ci][c][e] * x[c][p+d+e])

@@ -320,42 +320,6 @@ hipError_t launch_mod_sigmoid2(float* x, size_t rows, int ld, int c0, int c1, hi
     return hipGetLastError();
 }
 
-// 3x3 conv (pad 1, stride 1) of a channels-last map to ONE output channel: y[pix] = b + sum_taps <x[pix+tap][0:C], w[tap][0:C]>.
-// Used for the ipt_blk1 tail: conv_out1's slice over ipt1 (1x1, 48->1; birefnet.rs:374-375) composed at load time with
-// ipt_blk1.conv_out (3x3, 64->48; decoder.rs:45,54) — two linear maps with no activation between them (decoder.rs:52).
-// 16 lanes per pixel, one float4 of channels per lane and tap (C == 64).
-__global__ void conv3x3_to1_kernel(const float* __restrict__ x, int B, int H, int W, int ldx, const float* __restrict__ w,
-                                   float bias, float* __restrict__ y) {
-    const int sub = threadIdx.x & 15;
-    const size_t npix = (size_t)B * H * W;
-    const size_t grp = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const size_t ngrp = ((size_t)gridDim.x * blockDim.x) >> 4;
-    f32x4 wr[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) wr[t] = *reinterpret_cast<const f32x4*>(w + t * 64 + sub * 4);
-    for (size_t pix = grp; pix < npix; pix += ngrp) {
-        const int ox = (int)(pix % W);
-        const size_t t2 = pix / W;
-        const int oy = (int)(t2 % H);
-        const size_t b = t2 / H;
-        float acc = 0.f;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int iy = oy + ky - 1;
-            if ((unsigned)iy >= (unsigned)H) continue;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int ix = ox + kx - 1;
-                if ((unsigned)ix >= (unsigned)W) continue;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((b * H + iy) * W + ix) * ldx + sub * 4);
-                const f32x4 ww = wr[ky * 3 + kx];
-                acc += (v[0] * ww[0] + v[1] * ww[1]) + (v[2] * ww[2] + v[3] * ww[3]);
-            }
-        }
-        acc += __shfl_xor(acc, 8); acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 1);
-        if (sub == 0) y[pix] = acc + bias;
-    }
-}
 // composed ipt_blk1 head (brn_weights.cpp): one thread per output pixel, 75 taps on the 3 image planes (zero outside), the
 // kernel of the pixel's border case read through the scalar cache (uniform per wave except in the 1-pixel frame)
 __global__ void __launch_bounds__(256) head_stencil5x5_kernel(const float* __restrict__ img, int B, int H, int W,
@@ -390,15 +354,6 @@ hipError_t launch_head_stencil5x5(const float* img, int B, int H, int W, const f
     if (B <= 0 || H < 2 || W < 2) return hipErrorInvalidValue;
     dim3 grid((unsigned)((W + 63) / 64), (unsigned)((H + 3) / 4), (unsigned)B), block(256);
     hipLaunchKernelGGL(head_stencil5x5_kernel, grid, block, 0, s, img, B, H, W, k, bias, y);
-    return hipGetLastError();
-}
-
-hipError_t launch_conv3x3_to1(const float* x, int B, int H, int W, int C, int ldx, const float* w, float bias,
-                              float* y, hipStream_t s) {
-    if (C != 64) return hipErrorInvalidValue;
-    size_t blocks = ((size_t)B * H * W * 16 + 255) / 256;
-    if (blocks > 32768) blocks = 32768;
-    hipLaunchKernelGGL(conv3x3_to1_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, B, H, W, ldx, w, bias, y);
     return hipGetLastError();
 }
 
