@@ -42,9 +42,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--deform-mode", default="reference_cpu", choices=["reference_cpu", "deformable"])
-    ap.add_argument("--compute", default="f32_split2", choices=list(MODES),
+    ap.add_argument("--compute", default="f32_split3", choices=list(MODES),
                     help="arithmetic of the contraction kernels (include/birefnet_hip.h brn_dtype)")
-    ap.add_argument("--also", default="f32,f32_split3", help="comma list of other compute modes to time briefly on rank 0 at N=1 ('' = none)")
+    ap.add_argument("--also", default="f32_split2,f32", help="comma list of other compute modes to time briefly on rank 0 at N=1 ('' = none)")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra steps with per-launch HIP events for the roofline block")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off", "on"])
     ap.add_argument("--cpu-baseline-size", type=int, default=0, help="image side for the CPU oracle sample (0 = choose)")
@@ -121,11 +121,11 @@ def main():
         # HBM-side bytes per launch of the gemm family: PMC counters cannot be read from inside this process; the figure is
         # the committed rocprofv3 measurement of this very command (profiles/README.md), only quoted when the config matches
         traffic, traffic_note = None, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE not collected for this configuration"
-        tj = os.path.join(ROOT, "profiles", "r01b_gemm_traffic.json")
-        if os.path.exists(tj) and (B, S, args.compute, args.deform_mode) == (1, 1024, "f32_split2", "reference_cpu"):
+        tj = os.path.join(ROOT, "profiles", f"r01b_gemm_traffic_{args.compute.replace('f32_', '')}.json")
+        if os.path.exists(tj) and (B, S, args.deform_mode) == (1, 1024, "reference_cpu"):
             t = json.load(open(tj))
             traffic = round((t["hbm_read_gb_x2corrected"] + t["hbm_write_gb"]) * 1e9 / t["gemm_family_dispatches"])
-            traffic_note = ("bytes per launch, gemm family average, from profiles/r01b_pmc_hbm_b1_1024_split2.csv (FETCH_SIZE x2 "
+            traffic_note = (f"bytes per launch, gemm family average, from profiles/r01b_pmc_hbm_b1_1024_{args.compute.replace('f32_', '')}.csv (FETCH_SIZE x2 "
                             "gfx950 correction + WRITE_SIZE, separate passes); algorithmic bytes per launch = "
                             f"{round(by / n / max(1, launches // n))}")
         roof = {

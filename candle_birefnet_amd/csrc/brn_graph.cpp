@@ -62,7 +62,7 @@ void run_gemm(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* C, 
     GemmPlan pl = plan_gemm(M, w.N, w.K, w.wp ? w.planes : 0);
     if (a_planes || c_planes) {
         // P2 operands exist only on the warp-specialised 2-plane kernel; a P2 output cannot go through the split-K reduce pass
-        if (!(w.wp && w.planes == 2)) fail(BRN_ERR_INVALID_ARG, "P2 activation layout outside the f32_split2 mode");
+        if (!(w.wp && (w.planes == 2 || w.planes == 3))) fail(BRN_ERR_INVALID_ARG, "P activation layout outside the split modes");
         pl.cfg = 0;
         if (c_planes) { pl.splitk = 1; pl.ws_floats = 0; }
     }
@@ -171,8 +171,9 @@ static void swin_attention_multi(Ctx& c, const SwinBlockW& blk, const float* xn,
     int M = 0;
     for (int k = 0; k < nin; ++k) M += B * hs[k] * wsz[k];
     float* qkv = c.arena->alloc((size_t)M * 3 * C);
-    float* att = c.arena->alloc((size_t)M * C);
-    run_gemm(c, blk.qkv, xn, M, C, qkv, 3 * C, 0, nullptr, 0, 0, nullptr, 0, p2, 0);   // swin.rs:217 (pad rows are synthesised by the kernel)
+    const int ldp = p2 ? C * p2 / 2 : C;                                // row stride (floats) of a P-layout [M][C] buffer
+    float* att = c.arena->alloc((size_t)M * ldp);
+    run_gemm(c, blk.qkv, xn, M, ldp, qkv, 3 * C, 0, nullptr, 0, 0, nullptr, 0, p2, 0);   // swin.rs:217 (pad rows are synthesised by the kernel)
     if (!c.dry) {
         // one launch for all maps of the pass (full + half scale): fewer ramps and tails than one launch per geometry
         WindowAttnParams ps[2]{};
@@ -180,7 +181,7 @@ static void swin_attention_multi(Ctx& c, const SwinBlockW& blk, const float* xn,
         double nwin = 0.0;
         for (int k = 0; k < nin; ++k) {
             WindowAttnParams& p = ps[k];
-            p.qkv = qkv + off * 3 * C; p.qkv_bias = blk.qkv.bias; p.rel_table = blk.rel_table; p.out = att + off * C;
+            p.qkv = qkv + off * 3 * C; p.qkv_bias = blk.qkv.bias; p.rel_table = blk.rel_table; p.out = att + off * ldp;
             p.B = B; p.H = hs[k]; p.W = wsz[k]; p.C = C; p.heads = blk.heads;
             p.Hp = roundup(hs[k], 12); p.Wp = roundup(wsz[k], 12);   // swin.rs:359-360
             p.shift = shift; p.scale = 1.0f / sqrtf(32.0f);          // head_dim^-0.5 (swin.rs:134)
@@ -192,7 +193,7 @@ static void swin_attention_multi(Ctx& c, const SwinBlockW& blk, const float* xn,
         Bracket b(c, FAM_ATTENTION, nwin * 2.0 * 2.0 * 144 * 144 * 32, 4.0 * ((double)M * 4 * C), M, C, shift);
         BRN_LAUNCH(launch_window_attention2(ps[0], nin > 1 ? &ps[1] : nullptr, c.stream));
     }
-    run_gemm(c, blk.proj, att, M, C, y, C, 0, residual, C, 0, nullptr, 0, p2, 0);      // swin.rs:310 (+ shortcut, swin.rs:406)
+    run_gemm(c, blk.proj, att, M, ldp, y, C, 0, residual, C, 0, nullptr, 0, p2, 0);      // swin.rs:310 (+ shortcut, swin.rs:406)
     c.arena->release(mk);
 }
 
@@ -231,25 +232,36 @@ void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int 
         float* xnext = nullptr;
         if (st.has_down) xnext = c.arena->alloc((size_t)total(i + 1) * 2 * C);
         const size_t mk = c.arena->mark();
-        float* xn = c.arena->alloc((size_t)M * C);
+        // P layout (kernels/split_planes.h) of the blocks' GEMM inputs in the split modes: 2 planes = the fp32 row size, 3 planes = 1.5x
         const int hidden = st.blocks.empty() ? 4 * C : st.blocks[0].fc1.N;
-        float* hid = c.arena->alloc((size_t)M * hidden);
+        int stage_pl = 0;
+        if (!st.blocks.empty()) {
+            const SwinBlockW& b0 = st.blocks[0];
+            const int np = b0.qkv.planes;
+            // (3 planes = rows 1.5x as long: measured 2 % SLOWER per forward in f32_split3, whose kernel is not staging-bound: 2 only)
+            if (np == 2 && b0.qkv.wp && b0.proj.wp && b0.fc1.wp && b0.fc2.wp && C % 32 == 0 && hidden % 32 == 0) stage_pl = np;
+        }
+        const int ldx = stage_pl ? C * stage_pl / 2 : C, ldh = stage_pl ? hidden * stage_pl / 2 : hidden;
+        float* xn = c.arena->alloc((size_t)M * ldx);
+        float* hid = c.arena->alloc((size_t)M * ldh);
         for (size_t j = 0; j < st.blocks.size(); ++j) {
             const SwinBlockW& bk = st.blocks[j];
             const int shift = (j % 2 == 0) ? 0 : w.window / 2;                       // swin.rs:552
-            // mode f32_split2: every GEMM input of the block is written by its producer in the P2 layout (the two bf16 planes
-            // the GEMM would split out while staging), so the GEMMs' staging waves only copy
-            const int p2 = (bk.qkv.wp && bk.qkv.planes == 2 && bk.fc1.wp && bk.fc2.wp && bk.proj.wp && C % 32 == 0 && hidden % 32 == 0) ? 2 : 0;
-            run_layernorm(c, bk.norm1, x, M, C, xn, C, 0, p2);                        // swin.rs:355
+            // split modes: every GEMM input of the block is written by its producer in the P layout (the bf16 planes the GEMM
+            // would split out while staging), so the GEMMs' staging waves only copy
+            const int p2 = stage_pl;
+            run_layernorm(c, bk.norm1, x, M, C, xn, ldx, 0, p2);                      // swin.rs:355
             swin_attention_multi(c, bk, xn, B, nin, hh, ww, C, shift, x, x, p2);      // x = shortcut + attn (swin.rs:406)
-            run_layernorm(c, bk.norm2, x, M, C, xn, C, 0, p2);                        // swin.rs:407
-            run_gemm(c, bk.fc1, xn, M, C, hid, hidden, 0, nullptr, 0, 0, nullptr, 0, p2, p2);   // fc1 + gelu_erf (swin.rs:104-105)
-            run_gemm(c, bk.fc2, hid, M, hidden, x, C, 0, x, C, 0, nullptr, 0, p2, 0);  // x + fc2(...) (swin.rs:106,407)
+            run_layernorm(c, bk.norm2, x, M, C, xn, ldx, 0, p2);                      // swin.rs:407
+            run_gemm(c, bk.fc1, xn, M, ldx, hid, ldh, 0, nullptr, 0, 0, nullptr, 0, p2, p2);   // fc1 + gelu_erf (swin.rs:104-105)
+            run_gemm(c, bk.fc2, hid, M, ldh, x, C, 0, x, C, 0, nullptr, 0, p2, 0);     // x + fc2(...) (swin.rs:106,407)
         }
         // stage output = norm_i(x_out), pre-downsample (swin.rs:591,784-789); written into its consumer's window
         size_t off = 0, off2 = 0;
         float* pm = nullptr;
-        if (st.has_down) pm = c.arena->alloc((size_t)total(i + 1) * 4 * C);
+        const int pm_pl = (st.has_down && st.reduction.wp && st.reduction.planes == 2 && (4 * C) % 32 == 0) ? 2 : 0;
+        const int ldpm = pm_pl ? 4 * C * pm_pl / 2 : 4 * C;
+        if (st.has_down) pm = c.arena->alloc((size_t)total(i + 1) * ldpm);
         for (int k = 0; k < nin; ++k) {
             const Map& o = ins[k].outs[i];
             if (o.B != B || o.H != hh[k] || o.W != ww[k] || o.C != C) fail(BRN_ERR_INVALID_ARG, "swin output window %d has the wrong shape", i);
@@ -259,9 +271,9 @@ void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int 
                 const int M2 = rows(k, i + 1);
                 if (!c.dry) {
                     LayerNormParams p{};
-                    p.x = x + off * C; p.y = pm + off2 * 4 * C; p.rows = M2; p.C = 4 * C; p.gamma = st.down_norm.g; p.beta = st.down_norm.b;
-                    p.eps = 1e-5f; p.ldy = 4 * C; p.y_coff = 0; p.mode = 1; p.H = hh[k]; p.W = ww[k]; p.Cin = C;
-                    p.y_planes = (st.reduction.wp && st.reduction.planes == 2 && (4 * C) % 32 == 0) ? 2 : 0;   // P2 for the reduction GEMM
+                    p.x = x + off * C; p.y = pm + off2 * ldpm; p.rows = M2; p.C = 4 * C; p.gamma = st.down_norm.g; p.beta = st.down_norm.b;
+                    p.eps = 1e-5f; p.ldy = ldpm; p.y_coff = 0; p.mode = 1; p.H = hh[k]; p.W = ww[k]; p.Cin = C;
+                    p.y_planes = pm_pl;                                            // P layout for the reduction GEMM
                     Bracket b(c, FAM_LAYERNORM, 0.0, 8.0 * M2 * 4.0 * C);
                     BRN_LAUNCH(launch_layernorm(p, c.stream));
                 }
@@ -269,10 +281,7 @@ void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int 
             }
             off += rows(k, i);
         }
-        if (st.has_down) {
-            const int p2 = (st.reduction.wp && st.reduction.planes == 2 && (4 * C) % 32 == 0) ? 2 : 0;
-            run_gemm(c, st.reduction, pm, total(i + 1), 4 * C, xnext, 2 * C, 0, nullptr, 0, 0, nullptr, 0, p2, 0);
-        }
+        if (st.has_down) run_gemm(c, st.reduction, pm, total(i + 1), ldpm, xnext, 2 * C, 0, nullptr, 0, 0, nullptr, 0, pm_pl, 0);
         c.arena->release(mk);
         x = xnext;
     }

@@ -591,8 +591,8 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, const fl
         if (p.scale) v = v * sc + sh;
         v = act4(v, p.act);
         float* dst = p.C + (long)m * p.ldc + p.c_coff + n;
-        if (p.c_planes == 2) {              // the next GEMM reads the P2 layout (launch_gemm checked N, ldc, c_coff % 32 == 0, no R)
-            store_planes2(p.C + (long)m * p.ldc, p.c_coff + n, v);
+        if (p.c_planes) {                   // the next GEMM reads the P layout (launch_gemm checked N, c_coff % 32 == 0, no R)
+            store_planes_n(p.c_planes, p.C + (long)m * p.ldc, p.c_coff + n, v);
         } else if (vec) {
             if (p.R) v = v + *reinterpret_cast<const f32x4*>(p.R + (long)m * p.ldr + p.r_coff + n);
             *reinterpret_cast<f32x4*>(dst) = v;
@@ -623,11 +623,12 @@ template <int MODE, int NP, int KS, bool DIAG, bool APL>   // APL: A arrives in 
 // KS = k elements per LDS stage (32, or 16 to halve the stage when 3 planes must fit twice per CU)
 __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) {
     constexpr int BM = 128, BN = 128, WTM = 64, WTN = 64, TM = 2, TN = 2;
-    static_assert(!APL || (NP == 2 && MODE == GEMM_DENSE), "the P2 input layout is the 2-plane split of a dense A");
+    static_assert(!APL || ((NP == 2 || NP == 3) && MODE == GEMM_DENSE), "the P input layout is the NP-plane split of a dense A");
     constexpr int SLD = KS + 8;                     // bf16 per LDS row (16-byte pad: conflict-free b128 fragment reads)
     constexpr int KSTEPS = KS / 16;                 // MFMA k-steps per stage
     constexpr int NBUF = 2;                         // 2 x NP x 20 KB: two workgroups per CU at NP <= 2 (a 3-deep ring was slower: 1 WG/CU exposes each tile's prologue + epilogue)
-    constexpr int AQ = KS / 4, RPP = 256 / AQ, PA = BM / RPP;   // producers: 256 threads, AQ float4 per KS-float row
+    constexpr int AQ = KS / 4, RPP = 256 / AQ;                  // producers: 256 threads, AQ float4 per KS-float row
+    constexpr int PA = APL ? 2 * NP : BM / RPP;                 // P-layout input: 4 NP 16-byte chunks per (row, K tile), 128 rows / 256 threads
     constexpr int WQ = KS / 8, WRPP = 256 / WQ, PB = BN / WRPP; // WQ 16-byte chunks per KS-bf16 row
     constexpr int BUF = NP * (BM + BN) * SLD;       // bf16 elements per LDS buffer
     constexpr int EP_LD = BN + 4;                   // floats per row of the epilogue's LDS image of the C tile
@@ -672,12 +673,22 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
         long a_base[PA];
         int a_iy[PA], a_ix[PA];
         bool a_ok[PA];
+        int p_lds[PA];          // P-layout input: LDS element offset of this thread's i-th chunk (plane, row, 8-element column)
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
-            const int m = m0 + lrow + i * RPP;
+            int m = m0 + lrow + i * RPP;
+            p_lds[i] = 0;
+            if (APL) {
+                const int q = i * 256 + pt, row = q / (4 * NP), c = q - row * (4 * NP);   // chunk c of the row: plane c / 4, k = 8 (c % 4)
+                m = m0 + row;
+                p_lds[i] = ((c >> 2) * BM + row) * SLD + (c & 3) * 8;
+            }
             a_ok[i] = m < p.M;
             a_iy[i] = 0; a_ix[i] = 0;
-            if (MODE == GEMM_DENSE) {
+            if (APL) {
+                const int q = i * 256 + pt, row = q / (4 * NP), c = q - row * (4 * NP);
+                a_base[i] = (long)m * p.lda + c * 4;          // + 16 NP kt floats per K tile (gload)
+            } else if (MODE == GEMM_DENSE) {
                 a_base[i] = (long)m * p.lda;
             } else {
                 const int hw = p.Hout * p.Wout;
@@ -703,10 +714,10 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
                 for (int i = 0; i < PB; ++i)
                     qb[pl][i] = *reinterpret_cast<const bf16x8*>(wsrc + (long)i * WRPP * wrow_stride + (long)(kt0 + t) * (NP * 32) + pl * 32);
             if (APL) {
-                // row m's K tile = 128 bytes at float offset k0: 8 x 16-byte chunks, kq 0-3 = hi plane, kq 4-7 = lo plane
+                // row m's K tile = 64 NP bytes at float offset 16 NP kt: 4 NP 16-byte chunks, chunk c = plane c / 4, k = 8 (c % 4)
 #pragma unroll
                 for (int i = 0; i < PA; ++i)
-                    qa[i] = load4_masked(p.A + (a_ok[i] ? a_base[i] : 0) + k0 + kq * 4, a_ok[i], qm[i]);
+                    qa[i] = load4_masked(p.A + (a_ok[i] ? a_base[i] : 0) + (long)(kt0 + t) * (16 * NP), a_ok[i], qm[i]);
             } else if (MODE == GEMM_DENSE) {
 #pragma unroll
                 for (int i = 0; i < PA; ++i)
@@ -737,7 +748,7 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
                     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                     const unsigned keep = qm[i] != 0.f ? 0xffffffffu : 0u;
                     const u32x4 bits = __builtin_bit_cast(u32x4, qa[i]) & keep;
-                    *reinterpret_cast<u32x4*>(As + ((kq >> 2) * BM + lrow + i * RPP) * SLD + (kq & 3) * 8) = bits;
+                    *reinterpret_cast<u32x4*>(As + p_lds[i]) = bits;
                 }
             } else {
 #pragma unroll
@@ -871,10 +882,10 @@ static hipError_t launch_split_ws(const GemmParams& p, hipStream_t s) {
     dim3 grid(tiles), block(512);
     constexpr int KS = 32;                  // (16-deep stages were tried for 3 planes: registers, not LDS, cap residency; slower)
     if (p.a_planes) {
-        if constexpr (NP == 2) {
-            if (p.mode != GEMM_DENSE) return hipErrorInvalidValue;
-            if (p.abl || p.trace) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, 2, KS, true, true>), grid, block, 0, s, p);
-            else hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, 2, KS, false, true>), grid, block, 0, s, p);
+        if constexpr (NP == 2) {            // (the 3-plane form works too, but was 2 % slower per forward: rows 1.5x as long)
+            if (p.mode != GEMM_DENSE || p.a_planes != NP) return hipErrorInvalidValue;
+            if (NP == 2 && (p.abl || p.trace)) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, 2, KS, true, true>), grid, block, 0, s, p);
+            else hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, NP, KS, false, true>), grid, block, 0, s, p);
             return hipGetLastError();
         }
         return hipErrorInvalidValue;
@@ -1208,9 +1219,9 @@ hipError_t launch_gemm(const GemmParams& p_in, const GemmPlan& pl, float* ws, hi
     if (p.splitk > 1 && !ws) return hipErrorInvalidValue;
     if (p.a_planes || p.c_planes) {         // P2 layouts: 2-plane split mode, dense, on the warp-specialised kernel only
         const bool ws_cfg = pl.cfg == 6 || pl.cfg == 0 || pl.cfg == 3 || pl.cfg == 4 || pl.cfg == 5;
-        if (p.planes != 2 || !p.Wp || p.mode != GEMM_DENSE || !ws_cfg) return hipErrorInvalidValue;
-        if (p.a_planes && (p.a_planes != 2 || p.lda % 32 || p.a_coff)) return hipErrorInvalidValue;
-        if (p.c_planes && (p.c_planes != 2 || p.splitk > 1 || p.R || p.N % 32 || p.ldc % 32 || p.c_coff % 32)) return hipErrorInvalidValue;
+        if (!(p.planes == 2 || p.planes == 3) || !p.Wp || p.mode != GEMM_DENSE || !ws_cfg) return hipErrorInvalidValue;
+        if (p.a_planes && (p.a_planes != p.planes || p.lda % 16 || p.a_coff)) return hipErrorInvalidValue;
+        if (p.c_planes && (p.c_planes != p.planes || p.splitk > 1 || p.R || p.N % 32 || p.ldc % 16 || p.c_coff % 32)) return hipErrorInvalidValue;
     }
     hipError_t e;
     if (p.planes > 0 && p.Wp && (p.mode == GEMM_DENSE || p.mode == GEMM_CONV_NHWC)) {

@@ -39,16 +39,20 @@ __device__ __forceinline__ void split4(const f32x4_sp v, const float mask, bf16x
 }
 
 
-// "P2" activation layout (mode f32_split2): an fp32 matrix [M][K], K % 32 == 0, stored by its PRODUCER as the two bf16 planes the
-// GEMM would otherwise split out while staging it.  Same bytes per row as fp32: K tile kt (32 elements) of a row occupies
-// bytes [128 kt, 128 kt + 64) = 32 hi values, [128 kt + 64, 128 kt + 128) = 32 lo values.  `row` points at the row's first
-// byte, `col` (a multiple of 4) is the logical column of v[0].
-__device__ __forceinline__ void store_planes2(float* row, int col, const f32x4_sp v) {
-    bf16x4 sp[2];
-    split4<2>(v, 1.0f, sp);
-    char* base = reinterpret_cast<char*>(row) + (col >> 5) * 128 + (col & 31) * 2;
-    *reinterpret_cast<bf16x4*>(base) = sp[0];
-    *reinterpret_cast<bf16x4*>(base + 64) = sp[1];
+// "P" activation layout (modes f32_split2 / f32_split3): an fp32 matrix [M][K], K % 32 == 0, stored by its PRODUCER as the NP
+// bf16 planes the GEMM would otherwise split out while staging it.  K tile kt (32 elements) of a row occupies NP x 64 bytes:
+// plane p at bytes [64 NP kt + 64 p, + 64).  NP = 2 is byte-for-byte the size of the fp32 row (ld unchanged); NP = 3 rows are
+// 1.5x as long (ld = 3K/2 floats).  `row` points at the row's first byte, `col` (a multiple of 4) is the logical column of v[0].
+template <int NP>
+__device__ __forceinline__ void store_planes(float* row, int col, const f32x4_sp v) {
+    bf16x4 sp[NP];
+    split4<NP>(v, 1.0f, sp);
+    char* base = reinterpret_cast<char*>(row) + (col >> 5) * (64 * NP) + (col & 31) * 2;
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<bf16x4*>(base + 64 * pl) = sp[pl];
+}
+__device__ __forceinline__ void store_planes_n(int np, float* row, int col, const f32x4_sp v) {
+    if (np == 2) store_planes<2>(row, col, v); else store_planes<3>(row, col, v);
 }
 
 }  // namespace brn

@@ -153,9 +153,15 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_f32_kernel(const
         // lane holds O^T[d = 16*dt + 4g + r][query = li]; softmax denominator applied here (swin.rs:300,303)
         if (qsrc >= 0) {
             const float inv = 1.0f / sum;
-            float* op = p.out + (long)qsrc * C + head * HD + g * 4;
-            *reinterpret_cast<f32x4*>(op) = o0 * inv;
-            *reinterpret_cast<f32x4*>(op + 16) = o1 * inv;
+            if (p.out_planes == 3) {        // mode f32_split3: the proj GEMM reads the 3-plane P layout (rows 1.5x as long)
+                float* orow = p.out + (long)qsrc * (C + C / 2);
+                store_planes<3>(orow, head * HD + g * 4, o0 * inv);
+                store_planes<3>(orow, head * HD + 16 + g * 4, o1 * inv);
+            } else {
+                float* op = p.out + (long)qsrc * C + head * HD + g * 4;
+                *reinterpret_cast<f32x4*>(op) = o0 * inv;
+                *reinterpret_cast<f32x4*>(op + 16) = o1 * inv;
+            }
         }
     }
 }
@@ -364,10 +370,10 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_split_kernel(con
         }
         if (qsrc >= 0) {
             const float inv = 1.0f / sum;
-            if (p.out_planes == 2) {        // the proj GEMM reads the P2 layout: a head's 32 outputs are one K tile of the row
+            if (p.out_planes == 2) {        // the proj GEMM reads the P layout: a head's 32 outputs are one K tile of the row
                 float* orow = p.out + (long)qsrc * C;
-                store_planes2(orow, head * HD + g * 4, o0 * inv);
-                store_planes2(orow, head * HD + 16 + g * 4, o1 * inv);
+                store_planes<2>(orow, head * HD + g * 4, o0 * inv);
+                store_planes<2>(orow, head * HD + 16 + g * 4, o1 * inv);
             } else {
                 float* op = p.out + (long)qsrc * C + head * HD + g * 4;
                 *reinterpret_cast<f32x4*>(op) = o0 * inv;
@@ -390,7 +396,7 @@ hipError_t launch_window_attention2(const WindowAttnParams& p, const WindowAttnP
         if (check_attention(*p2) != hipSuccess || p2->C != p.C || p2->heads != p.heads || p2->planes != p.planes || p2->out_planes != p.out_planes) return hipErrorInvalidValue;
         n1 = p2->B * (p2->Hp / WS) * (p2->Wp / WS);
     }
-    if (p.out_planes && (p.out_planes != 2 || p.planes != 2)) return hipErrorInvalidValue;
+    if (p.out_planes && !((p.out_planes == 2 && p.planes == 2) || (p.out_planes == 3 && p.planes == 0))) return hipErrorInvalidValue;
     const WindowAttnParams& q = p2 ? *p2 : p;
     dim3 grid(n0 + n1, p.heads), block(ATT_THREADS);
     if (p.planes == 2) hipLaunchKernelGGL(window_attention_split_kernel<2>, grid, block, 0, s, p, q, n0);
