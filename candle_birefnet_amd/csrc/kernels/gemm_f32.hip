@@ -700,7 +700,8 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
             }
         }
         const int wc = pt % WQ, wrow = pt / WQ;
-        static_assert(KS == 32, "the interleaved W plane layout is per 32-deep K tile");
+        static_assert(KS == 32 || KS == 16, "the interleaved W plane layout is per 32-deep K tile; a 16-deep stage takes one half of it");
+        static_assert(!APL || KS == 32, "P-layout input is staged in whole 32-deep K tiles");
         const long wrow_stride = (long)p.K * NP;         // W planes interleaved per K tile: [row][K/32][plane][32] bf16
         const __bf16* wsrc = reinterpret_cast<const __bf16*>(p.Wp) + (long)(n0 + wrow) * wrow_stride + wc * 8;
         f32x4 ra[2][PA];
@@ -712,7 +713,9 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
             for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
                 for (int i = 0; i < PB; ++i)
-                    qb[pl][i] = *reinterpret_cast<const bf16x8*>(wsrc + (long)i * WRPP * wrow_stride + (long)(kt0 + t) * (NP * 32) + pl * 32);
+                    qb[pl][i] = *reinterpret_cast<const bf16x8*>(wsrc + (long)i * WRPP * wrow_stride +
+                                                                 (KS == 32 ? (long)(kt0 + t) * (NP * 32) + pl * 32
+                                                                           : (long)((kt0 + t) >> 1) * (NP * 32) + pl * 32 + ((kt0 + t) & 1) * 16));
             if (APL) {
                 // row m's K tile = 64 NP bytes at float offset 16 NP kt: 4 NP 16-byte chunks, chunk c = plane c / 4, k = 8 (c % 4)
 #pragma unroll
@@ -876,25 +879,32 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
     if (trc && tid == 0) { trc[5] = clock64(); trc[6] = wall_clock64(); }
 }
 
-template <int NP>
-static hipError_t launch_split_ws(const GemmParams& p, hipStream_t s) {
-    const int tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128) * p.splitk;
-    dim3 grid(tiles), block(512);
-    constexpr int KS = 32;                  // (16-deep stages were tried for 3 planes: registers, not LDS, cap residency; slower)
+template <int NP, int KS>
+static hipError_t launch_split_ws_ks(const GemmParams& p, dim3 grid, hipStream_t s) {
+    const dim3 block(512);
     if (p.a_planes) {
-        if constexpr (NP == 2) {            // (the 3-plane form works too, but was 2 % slower per forward: rows 1.5x as long)
+        if constexpr (NP == 2 && KS == 32) {   // (the 3-plane form works too, but was 2 % slower per forward: rows 1.5x as long)
             if (p.mode != GEMM_DENSE || p.a_planes != NP) return hipErrorInvalidValue;
-            if (NP == 2 && (p.abl || p.trace)) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, 2, KS, true, true>), grid, block, 0, s, p);
-            else hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, NP, KS, false, true>), grid, block, 0, s, p);
+            if (p.abl || p.trace) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, 2, 32, true, true>), grid, block, 0, s, p);
+            else hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, 2, 32, false, true>), grid, block, 0, s, p);
             return hipGetLastError();
         }
         return hipErrorInvalidValue;
     }
-    if (p.mode == GEMM_DENSE && (p.abl || p.trace)) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, NP, KS, true, false>), grid, block, 0, s, p);
+    if (p.mode == GEMM_DENSE && KS == 32 && (p.abl || p.trace)) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, NP, 32, true, false>), grid, block, 0, s, p);
     else if (p.mode == GEMM_DENSE) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, NP, KS, false, false>), grid, block, 0, s, p);
     else if (p.mode == GEMM_CONV_NHWC) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_CONV_NHWC, NP, KS, false, false>), grid, block, 0, s, p);
     else return hipErrorInvalidValue;
     return hipGetLastError();
+}
+template <int NP>
+static hipError_t launch_split_ws(const GemmParams& p, hipStream_t s) {
+    const int tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128) * p.splitk;
+    const dim3 grid(tiles);
+    // 3 planes: 32-deep stages need 120 KB of LDS (one workgroup per CU); 16-deep stages (2 x 36 KB) let two share a CU like the
+    // 2-plane kernel's do, at twice the barriers per K: worth it as soon as there is more than one workgroup per CU to place
+    if (NP == 3 && tiles > 256 && !(p.abl || p.trace)) return launch_split_ws_ks<NP, 16>(p, grid, s);
+    return launch_split_ws_ks<NP, 32>(p, grid, s);
 }
 
 template <int BM, int BN, int WM, int WN, int NP>
