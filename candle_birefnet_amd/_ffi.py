@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("BRN_LIB_PATH") or os.path.join(_HERE, "libbirefnet_hi
 
 BRN_OK = 0
 BRN_MEM_HOST, BRN_MEM_DEVICE = 0, 1
-BRN_F32, BRN_F32_SPLIT3, BRN_F32_SPLIT2, BRN_BF16_OPERANDS = 0, 1, 2, 3
+BRN_F32, BRN_F32_SPLIT3, BRN_F32_SPLIT2, BRN_BF16_OPERANDS, BRN_BF16 = 0, 1, 2, 3, 4
 BRN_DEFORM_REFERENCE_CPU, BRN_DEFORM_DEFORMABLE = 0, 1
 BRN_ACT_NONE, BRN_ACT_RELU, BRN_ACT_GELU_ERF = 0, 1, 2
 
@@ -105,7 +105,8 @@ _sig("brn_deform_conv2d_forward", C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_i
 _sig("brn_preprocess_image", C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp)
 _sig("brn_postprocess_mask", C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp)
 _sig("brn_set_op_compute", C.c_int, C.c_int)
-_sig("brn_gemm_microbench", C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float))
+if hasattr(lib, "brn_gemm_microbench"):   # only in libbirefnet_hip_diag.so (make diag; include/birefnet_hip_diag.h), reached through BRN_LIB_PATH
+    _sig("brn_gemm_microbench", C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float))
 
 # every symbol include/birefnet_hip.h declares (checked by tests/test_abi.py against the header text)
 DECLARED = [
@@ -115,7 +116,7 @@ DECLARED = [
     "brn_model_set_profiling", "brn_model_last_timings", "brn_model_last_kernel_stats", "brn_kernel_family_name",
     "brn_swin_create", "brn_swin_destroy", "brn_swin_forward", "brn_linear_forward", "brn_layer_norm_forward",
     "brn_conv2d_forward", "brn_upsample_bilinear2d", "brn_window_attention_forward", "brn_patch_merging_forward",
-    "brn_deform_conv2d_forward", "brn_gemm_microbench", "brn_set_op_compute", "brn_preprocess_image", "brn_postprocess_mask",
+    "brn_deform_conv2d_forward", "brn_set_op_compute", "brn_preprocess_image", "brn_postprocess_mask",
 ]
 
 

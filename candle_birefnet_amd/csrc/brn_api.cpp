@@ -67,10 +67,11 @@ struct Staging {
 };
 
 // run a graph fragment with a private arena: plan (dry), allocate, run
-static void with_arena(hipStream_t s, const std::function<void(Ctx&)>& fn) {
+static void with_arena(hipStream_t s, const std::function<void(Ctx&)>& fn, bool bf16 = false) {
     Arena a;
     a.dry = true;
     Ctx c{&a, s, true, false, nullptr, nullptr, nullptr};
+    c.bf16 = bf16;
     fn(c);
     Arena real;
     real.cap = a.peak + 256;
@@ -79,6 +80,7 @@ static void with_arena(hipStream_t s, const std::function<void(Ctx&)>& fn) {
     if (e != hipSuccess) fail(BRN_ERR_OOM, "workspace hipMalloc of %zu bytes failed: %s", real.cap, hipGetErrorString(e));
     real.base = (char*)d;
     Ctx c2{&real, s, false, false, nullptr, nullptr, nullptr};
+    c2.bf16 = bf16;
     try {
         fn(c2);
         BRN_HIP(hipStreamSynchronize(s));
@@ -96,6 +98,7 @@ static void plan_model(Model& m, int B, int H, int W) {
     Arena dry;
     dry.dry = true;
     Ctx c{&dry, nullptr, true, false, nullptr, nullptr, nullptr};
+    c.bf16 = m.bf16;
     model_forward(m, c, nullptr, pb, ph, pw, nullptr, 0);
     size_t need = dry.peak + 4096;
     // staging for host-resident input / output of the full model
@@ -151,6 +154,8 @@ static void run_model(Model* m, const float* x, int B, int H, int W, brn_mem in_
     BRN_HIP(hipSetDevice(m->device));
     hipStream_t s = (hipStream_t)stream;
     plan_model(*m, B, H, W);
+    if (!m->done_ev) BRN_HIP(hipEventCreateWithFlags(&m->done_ev, hipEventDisableTiming));
+    if (m->has_last && m->last_stream != s) BRN_HIP(hipStreamWaitEvent(s, m->done_ev, 0));   // previous forward still owns the arena
     m->arena.top = 0;
     const size_t n_in = (size_t)B * 3 * H * W, n_out = (size_t)B * H * W;
     const float* dx = x;
@@ -167,11 +172,14 @@ static void run_model(Model* m, const float* x, int B, int H, int W, brn_mem in_
         m->stage_ev_ok = true;
     }
     Ctx c{&m->arena, s, false, m->profiling, &m->records, &m->event_pool, &m->event_next};
+    c.bf16 = m->bf16;
     model_forward(*m, c, dx, B, H, W, dout, apply_sigmoid);
     if (out_loc == BRN_MEM_HOST) {
         BRN_HIP(hipMemcpyAsync(out, dout, n_out * sizeof(float), hipMemcpyDeviceToHost, s));
         BRN_HIP(hipStreamSynchronize(s));
     }
+    BRN_HIP(hipEventRecord(m->done_ev, s));
+    m->last_stream = s; m->has_last = true;
     if (m->profiling) collect_profile(*m, s);
 }
 
@@ -234,6 +242,7 @@ brn_status brn_model_create(const brn_config* cfg, const brn_named_tensor* weigh
         else if (dt == BRN_F32_SPLIT3) planes = 3;
         else if (dt == BRN_F32_SPLIT2) planes = 2;
         else if (dt == BRN_BF16_OPERANDS) planes = 1;
+        else if (dt == BRN_BF16) planes = BUILD_BF16;
         else fail(BRN_ERR_INVALID_ARG, "unsupported compute dtype %d", (int)dt);
         struct PlanesGuard { PlanesGuard(int p) { set_build_planes(p); } ~PlanesGuard() { set_build_planes(0); } } guard(planes);
         *out = nullptr;
@@ -241,7 +250,7 @@ brn_status brn_model_create(const brn_config* cfg, const brn_named_tensor* weigh
         validate_config(*cfg);
         std::unique_ptr<brn_model> h(new brn_model());
         Model& m = h->m;
-        m.cfg = *cfg; m.device = device;
+        m.cfg = *cfg; m.device = device; m.bf16 = dt == BRN_BF16;
         WeightTable wt(weights, n);
         build_swin_weights(wt, "bb.", *cfg, m.own, m.swin);                               // birefnet.rs:393
         int lat[4];
@@ -320,11 +329,11 @@ static void swin_outputs_nchw(Ctx& c, const SwinW& w, const float* dx, int B, in
     swin_forward(c, w, dx, B, H, W, hm);
     if (!c.dry)
         for (int i = 0; i < 4; ++i)     // NHWC -> NCHW: the permute(0,3,1,2) of swin.rs:786-788
-            BRN_HIP(launch_nhwc_to_nchw(hm[i].p, B, hm[i].C, hs[i], ws[i], hm[i].ld, 0, douts[i], c.stream));
+            BRN_HIP(launch_nhwc_to_nchw(hm[i].p, B, hm[i].C, hs[i], ws[i], hm[i].ld, 0, douts[i], c.stream, c.bf16));
 }
 
 static void swin_entry(const SwinW& w, int device, const float* x, int B, int H, int W, brn_mem in_loc, float* const outs[4],
-                       brn_mem out_loc, void* stream) {
+                       brn_mem out_loc, void* stream, bool bf16 = false) {
     if (!x || !outs) fail(BRN_ERR_INVALID_ARG, "null argument");
     if (B < 1 || H < 1 || W < 1) fail(BRN_ERR_INVALID_ARG, "bad input shape");
     BRN_HIP(hipSetDevice(device));
@@ -334,7 +343,7 @@ static void swin_entry(const SwinW& w, int device, const float* x, int B, int H,
     swin_stage_dims(H, W, w.patch, hs, ws);
     float* douts[4];
     for (int i = 0; i < 4; ++i) douts[i] = so.out(outs[i], (size_t)B * (w.embed_dim << i) * hs[i] * ws[i]);
-    with_arena((hipStream_t)stream, [&](Ctx& c) { swin_outputs_nchw(c, w, dx, B, H, W, douts); });
+    with_arena((hipStream_t)stream, [&](Ctx& c) { swin_outputs_nchw(c, w, dx, B, H, W, douts); }, bf16);
     so.finish();
 }
 
@@ -343,7 +352,7 @@ brn_status brn_model_backbone_forward(brn_model* m, const float* x, int B, int H
     return guarded([&] {
         if (!m) fail(BRN_ERR_INVALID_ARG, "null model");
         std::lock_guard<std::mutex> lk(m->m.mu);
-        swin_entry(m->m.swin, m->m.device, x, B, H, W, in_loc, outs, out_loc, stream);
+        swin_entry(m->m.swin, m->m.device, x, B, H, W, in_loc, outs, out_loc, stream, m->m.bf16);
     });
 }
 
@@ -359,10 +368,10 @@ brn_status brn_model_squeeze_forward(brn_model* m, const float* x4, int B, int h
         float* dy = so.out(out, (size_t)B * cout * h * w);
         with_arena((hipStream_t)stream, [&](Ctx& c) {
             Map X = new_map(c, B, h, w, cin), Y = new_map(c, B, h, w, cout);
-            if (!c.dry) BRN_HIP(launch_nchw_to_nhwc(dx, B, cin, h, w, X.p, X.ld, 0, c.stream));
+            if (!c.dry) BRN_HIP(launch_nchw_to_nhwc(dx, B, cin, h, w, X.p, X.ld, 0, c.stream, c.bf16));
             decblk_forward(c, m->m.squeeze, X, Y, m->m.cfg.deform_mode);
-            if (!c.dry) BRN_HIP(launch_nhwc_to_nchw(Y.p, B, cout, h, w, Y.ld, 0, dy, c.stream));
-        });
+            if (!c.dry) BRN_HIP(launch_nhwc_to_nchw(Y.p, B, cout, h, w, Y.ld, 0, dy, c.stream, c.bf16));
+        }, m->m.bf16);
         so.finish();
     });
 }
@@ -387,13 +396,13 @@ brn_status brn_model_decoder_forward(brn_model* m, const float* x, const float* 
             Map X1 = new_map(c, B, hh[0], ww[0], 384), X2 = new_map(c, B, hh[1], ww[1], 768), X3 = new_map(c, B, hh[2], ww[2], 1536);
             Map D4 = new_map(c, B, hh[3], ww[3], 3456);
             if (!c.dry) {
-                BRN_HIP(launch_nchw_to_nhwc(dsrc[0], B, 384, hh[0], ww[0], X1.p, X1.ld, 0, c.stream));
-                BRN_HIP(launch_nchw_to_nhwc(dsrc[1], B, 768, hh[1], ww[1], X2.p, X2.ld, 0, c.stream));
-                BRN_HIP(launch_nchw_to_nhwc(dsrc[2], B, 1536, hh[2], ww[2], X3.p, X3.ld, 0, c.stream));
-                BRN_HIP(launch_nchw_to_nhwc(dsrc[3], B, 3072, hh[3], ww[3], D4.p, D4.ld, 0, c.stream));
+                BRN_HIP(launch_nchw_to_nhwc(dsrc[0], B, 384, hh[0], ww[0], X1.p, X1.ld, 0, c.stream, c.bf16));
+                BRN_HIP(launch_nchw_to_nhwc(dsrc[1], B, 768, hh[1], ww[1], X2.p, X2.ld, 0, c.stream, c.bf16));
+                BRN_HIP(launch_nchw_to_nhwc(dsrc[2], B, 1536, hh[2], ww[2], X3.p, X3.ld, 0, c.stream, c.bf16));
+                BRN_HIP(launch_nchw_to_nhwc(dsrc[3], B, 3072, hh[3], ww[3], D4.p, D4.ld, 0, c.stream, c.bf16));
             }
             decoder_forward(c, m->m, dx, B, H, W, X1, X2, X3, D4, dy, 0);
-        });
+        }, m->m.bf16);
         so.finish();
     });
 }
@@ -552,6 +561,7 @@ brn_status brn_set_op_compute(int dtype) {
         else if (dtype == BRN_F32_SPLIT3) g_op_planes = 3;
         else if (dtype == BRN_F32_SPLIT2) g_op_planes = 2;
         else if (dtype == BRN_BF16_OPERANDS) g_op_planes = 1;
+        else if (dtype == BRN_BF16) g_op_planes = BUILD_BF16;
         else fail(BRN_ERR_INVALID_ARG, "unsupported compute dtype %d", dtype);
     });
 }
@@ -570,6 +580,15 @@ brn_status brn_linear_forward(const float* x, int M, int K, const float* w, cons
         const float* dx = st.in(x, (size_t)M * K);
         const float* dr = residual ? st.in(residual, (size_t)M * N) : nullptr;
         float* dy = st.out(y, (size_t)M * N);
+        if (g_op_planes == BUILD_BF16) {
+            // compute mode BRN_BF16 at op level: x is rounded to bf16 at the edge (as the producing kernel of the model would have
+            // written it), the product runs on kernels/gemm_bf16.hip, y (and the residual) stay fp32 at this boundary
+            with_arena((hipStream_t)stream, [&](Ctx& c) {
+                float* xb = c.arena->alloc_bytes((size_t)M * K * 2);
+                if (!c.dry) BRN_HIP(launch_f32_to_bf16(dx, (size_t)M * K, xb, c.stream));
+                run_gemm(c, g, xb, M, K, dy, N, 0, dr, N, 0, nullptr, 0, 0, 0, 1, 1);
+            }, true);
+        } else
         with_arena((hipStream_t)stream, [&](Ctx& c) { run_gemm(c, g, dx, M, K, dy, N, 0, dr, N, 0); });
         st.finish();
     });
@@ -614,17 +633,18 @@ brn_status brn_conv2d_forward(const float* x, int B, int C, int H, int W, const 
         Staging st(stream, loc);
         const float* dx = st.in(x, (size_t)B * C * H * W);
         float* dy = st.out(y, (size_t)B * O * Ho * Wo);
+        const bool bf = g_op_planes == BUILD_BF16 && nhwc && C >= 64;   // bf16 mode: bf16 map in, bf16 map out, like inside the model
         with_arena((hipStream_t)stream, [&](Ctx& c) {
             Map Y = new_map(c, B, Ho, Wo, O);
             if (nhwc) {
                 Map X = new_map(c, B, H, W, C);
-                if (!c.dry) BRN_HIP(launch_nchw_to_nhwc(dx, B, C, H, W, X.p, X.ld, 0, c.stream));
+                if (!c.dry) BRN_HIP(launch_nchw_to_nhwc(dx, B, C, H, W, X.p, X.ld, 0, c.stream, c.bf16));
                 run_conv(c, g, X, Y);
             } else {
                 run_conv_nchw(c, g, dx, B, H, W, Y);
             }
-            if (!c.dry) BRN_HIP(launch_nhwc_to_nchw(Y.p, B, O, Ho, Wo, Y.ld, 0, dy, c.stream));
-        });
+            if (!c.dry) BRN_HIP(launch_nhwc_to_nchw(Y.p, B, O, Ho, Wo, Y.ld, 0, dy, c.stream, c.bf16));
+        }, bf);
         st.finish();
     });
 }
@@ -743,169 +763,6 @@ brn_status brn_deform_conv2d_forward(const float* x, int B, int C, int H, int W,
             if (!c.dry) BRN_HIP(launch_nhwc_to_nchw(Y.p, B, O, Ho, Wo, Y.ld, 0, dy, c.stream));
         });
         st.finish();
-    });
-}
-
-// ---- diagnostics -----------------------------------------------------------------------------------------------------
-brn_status brn_gemm_microbench(int M, int N, int K, int tile_cfg, int splitk, int iters, int device, float* ms_per_launch) {
-    return guarded([&] {
-        if (tile_cfg >= 130 && tile_cfg < 140) {   // MFMA / VALU SIMD-sharing probe, mode = tile_cfg - 130; returns us per launch
-            ensure_device(device);
-            DeviceOwner own;
-            std::vector<float> z(16, 0.f);
-            float* sink = own.upload(z);
-            hipEvent_t e0, e1;
-            BRN_HIP(hipEventCreate(&e0)); BRN_HIP(hipEventCreate(&e1));
-            BRN_HIP(launch_mfma_valu_probe(M, N, tile_cfg - 130, sink, nullptr));
-            BRN_HIP(hipEventRecord(e0, nullptr));
-            for (int i = 0; i < iters; ++i) BRN_HIP(launch_mfma_valu_probe(M, N, tile_cfg - 130, sink, nullptr));
-            BRN_HIP(hipEventRecord(e1, nullptr));
-            BRN_HIP(hipEventSynchronize(e1));
-            float ms = 0.f;
-            BRN_HIP(hipEventElapsedTime(&ms, e0, e1));
-            ms_per_launch[0] = ms / iters * 1e3f;
-            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-            return;
-        }
-        if (tile_cfg >= 110 && tile_cfg < 130) {   // LDS-fragment + MFMA consumer-loop probe: 11x = variant 0, 12x = variant 1, x = planes
-            ensure_device(device);
-            DeviceOwner own;
-            std::vector<float> z(16, 0.f);
-            float* sink = own.upload(z);
-            const int np = tile_cfg % 10, variant = tile_cfg >= 120;
-            hipEvent_t e0, e1;
-            BRN_HIP(hipEventCreate(&e0)); BRN_HIP(hipEventCreate(&e1));
-            BRN_HIP(launch_lds_mfma_probe(M, N, np, variant, sink, nullptr));
-            BRN_HIP(hipEventRecord(e0, nullptr));
-            for (int i = 0; i < iters; ++i) BRN_HIP(launch_lds_mfma_probe(M, N, np, variant, sink, nullptr));
-            BRN_HIP(hipEventRecord(e1, nullptr));
-            BRN_HIP(hipEventSynchronize(e1));
-            float ms = 0.f;
-            BRN_HIP(hipEventElapsedTime(&ms, e0, e1));
-            const int npair = np * (np + 1) / 2;
-            const double mfmas = (double)M * 4 * (double)N * 2 * 4 * npair;      // wgs * waves * iters * ksteps * tiles * pairs
-            ms_per_launch[0] = (float)(mfmas * 32768.0 / (ms / iters * 1e-3) / 1e12);   // bf16 TF/s
-            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-            return;
-        }
-        if (tile_cfg == 101 || tile_cfg == 102) {   // bf16 32x32x16 MFMA peak probe (101: 4 accumulators, 102: one dependent chain)
-            ensure_device(device);
-            DeviceOwner own;
-            std::vector<float> z(16, 0.f);
-            float* sink = own.upload(z);
-            unsigned long long* clk = (unsigned long long*)own.upload(z);
-            hipEvent_t e0, e1;
-            BRN_HIP(hipEventCreate(&e0)); BRN_HIP(hipEventCreate(&e1));
-            const int nacc = tile_cfg == 101 ? 4 : 1;
-            BRN_HIP(launch_mfma_peak_bf16(M, N, sink, clk, nacc, nullptr));
-            BRN_HIP(hipEventRecord(e0, nullptr));
-            for (int i = 0; i < iters; ++i) BRN_HIP(launch_mfma_peak_bf16(M, N, sink, clk, nacc, nullptr));
-            BRN_HIP(hipEventRecord(e1, nullptr));
-            BRN_HIP(hipEventSynchronize(e1));
-            float ms = 0.f;
-            BRN_HIP(hipEventElapsedTime(&ms, e0, e1));
-            unsigned long long hc[2];
-            BRN_HIP(hipMemcpy(hc, clk, sizeof hc, hipMemcpyDeviceToHost));
-            const double flop = (double)M * 4 * (double)N * 4 * 32768.0;
-            ms_per_launch[0] = (float)(flop / (ms / iters * 1e-3) / 1e12);
-            if (K > 1) ms_per_launch[1] = hc[1] ? (float)((double)hc[0] / (double)hc[1] * 100.0) : 0.f;
-            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-            return;
-        }
-        if (tile_cfg == 100) {   // MFMA peak probe: M = workgroups, N = MFMA iterations (x4) per wave; returns TF/s, clock via splitk ptr hack-free
-            ensure_device(device);
-            DeviceOwner own;
-            std::vector<float> z(16, 0.f);
-            float* sink = own.upload(z);
-            unsigned long long* clk = (unsigned long long*)own.upload(z);
-            hipEvent_t e0, e1;
-            BRN_HIP(hipEventCreate(&e0)); BRN_HIP(hipEventCreate(&e1));
-            BRN_HIP(launch_mfma_peak(M, N, sink, clk, nullptr));
-            BRN_HIP(hipEventRecord(e0, nullptr));
-            for (int i = 0; i < iters; ++i) BRN_HIP(launch_mfma_peak(M, N, sink, clk, nullptr));
-            BRN_HIP(hipEventRecord(e1, nullptr));
-            BRN_HIP(hipEventSynchronize(e1));
-            float ms = 0.f;
-            BRN_HIP(hipEventElapsedTime(&ms, e0, e1));
-            unsigned long long hc[2];
-            BRN_HIP(hipMemcpy(hc, clk, sizeof hc, hipMemcpyDeviceToHost));
-            const double flop = (double)M * 4 /*waves*/ * (double)N * 4 * 4096.0;
-            ms_per_launch[0] = (float)(flop / (ms / iters * 1e-3) / 1e12);                    // TF/s
-            if (K > 1) ms_per_launch[1] = hc[1] ? (float)((double)hc[0] / (double)hc[1] * 100.0) : 0.f;   // MHz (K>1: 2 floats out)
-            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-            return;
-        }
-        if (M < 1 || N < 1 || K < 32 || K % 32 || iters < 1 || !ms_per_launch) fail(BRN_ERR_INVALID_ARG, "bad argument");
-        ensure_device(device);
-        DeviceOwner own;
-        std::vector<float> ha((size_t)M * K), hw((size_t)((N + 127) / 128 * 128) * K, 0.f);
-        uint32_t s = 12345u;
-        auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xFFFF) / 32768.0f - 1.0f; };
-        for (auto& v : ha) v = rnd();
-        for (size_t i = 0; i < (size_t)N * K; ++i) hw[i] = rnd();
-        int planes = 0;
-        if (tile_cfg >= 1000) { planes = tile_cfg / 1000; tile_cfg %= 1000; if (tile_cfg == 999) tile_cfg = -1; }
-        float* dA = own.upload(ha);
-        set_build_planes(planes);
-        GemmW gw = make_linear(own, hw.data(), nullptr, N, K);
-        set_build_planes(0);
-        float* dW = gw.w;
-        std::vector<float> hc((size_t)M * N, 0.f);
-        float* dC = own.upload(hc);
-        GemmPlan pl = plan_gemm(M, N, K, gw.wp ? gw.planes : 0);
-        bool a_p2 = false;
-        if (tile_cfg == 9) { tile_cfg = 0; a_p2 = true; }     // 2009: warp-specialised kernel fed an A that is already in the P2 layout
-        if (tile_cfg >= 0) { pl.cfg = tile_cfg; pl.splitk = splitk > 1 ? splitk : 1; pl.ws_floats = pl.splitk > 1 ? (size_t)pl.splitk * M * N : 0; }
-        if (a_p2) {
-            if (planes != 2 || K % 32) fail(BRN_ERR_INVALID_ARG, "P2 input needs the 2-plane mode");
-            auto bf = [](float x) { uint32_t u; std::memcpy(&u, &x, 4); const uint32_t r = u + 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(r >> 16); };
-            auto fl = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; };
-            std::vector<float> p2(ha.size());
-            uint16_t* q = reinterpret_cast<uint16_t*>(p2.data());
-            for (int m = 0; m < M; ++m)
-                for (int k = 0; k < K; ++k) {
-                    const float x = ha[(size_t)m * K + k];
-                    const uint16_t h = bf(x), l = bf(x - fl(h));
-                    uint16_t* row = q + (size_t)m * K * 2;
-                    row[(k / 32) * 64 + (k % 32)] = h;
-                    row[(k / 32) * 64 + 32 + (k % 32)] = l;
-                }
-            BRN_HIP(hipMemcpy(dA, p2.data(), p2.size() * 4, hipMemcpyHostToDevice));
-        }
-        float* ws = nullptr;
-        if (pl.ws_floats) { std::vector<float> z(pl.ws_floats, 0.f); ws = own.upload(z); }
-        GemmParams p{};
-        p.A = dA; p.W = dW; p.C = dC; p.M = M; p.N = N; p.K = K; p.mode = GEMM_DENSE; p.lda = K; p.ldc = N; p.bbias_rows = 1;
-        p.Wp = gw.wp; p.planes = gw.planes; p.wp_rows = gw.wp_rows;
-        p.a_planes = a_p2 ? 2 : 0;
-        if (const char* ab = getenv("BRN_GEMM_ABLATE")) p.abl = atoi(ab);
-        std::vector<float> hb((size_t)N, 0.1f);
-        if (const char* ac = getenv("BRN_GEMM_ACT")) { p.act = atoi(ac); p.bias = own.upload(hb); }          // epilogue cost probes
-        if (getenv("BRN_GEMM_RES")) { p.R = dC; p.ldr = N; }
-        hipEvent_t e0, e1;
-        BRN_HIP(hipEventCreate(&e0)); BRN_HIP(hipEventCreate(&e1));
-        for (int i = 0; i < 3; ++i) BRN_HIP(launch_gemm(p, pl, ws, nullptr));
-        BRN_HIP(hipEventRecord(e0, nullptr));
-        for (int i = 0; i < iters; ++i) BRN_HIP(launch_gemm(p, pl, ws, nullptr));
-        BRN_HIP(hipEventRecord(e1, nullptr));
-        BRN_HIP(hipEventSynchronize(e1));
-        float ms = 0.f;
-        BRN_HIP(hipEventElapsedTime(&ms, e0, e1));
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-        *ms_per_launch = ms / iters;
-        if (const char* tp = getenv("BRN_GEMM_TRACE")) {   // one more launch with per-workgroup cycle stamps, dumped raw
-            const size_t nwg = (size_t)((M + 127) / 128) * ((N + 127) / 128) * (size_t)std::max(1, pl.splitk);
-            std::vector<unsigned long long> tr(nwg * 256, 0ull);
-            unsigned long long* dtr = nullptr;
-            BRN_HIP(hipMalloc(&dtr, tr.size() * 8));
-            BRN_HIP(hipMemset(dtr, 0, tr.size() * 8));
-            p.trace = dtr;
-            BRN_HIP(launch_gemm(p, pl, ws, nullptr));
-            BRN_HIP(hipDeviceSynchronize());
-            BRN_HIP(hipMemcpy(tr.data(), dtr, tr.size() * 8, hipMemcpyDeviceToHost));
-            (void)hipFree(dtr);
-            if (FILE* f = fopen(tp, "wb")) { fwrite(tr.data(), 8, tr.size(), f); fclose(f); }
-        }
     });
 }
 

@@ -24,7 +24,7 @@ float* Arena::alloc(size_t nfloats) {
 Map new_map(Ctx& c, int B, int H, int W, int C) {
     Map m;
     m.B = B; m.H = H; m.W = W; m.C = C; m.ld = C; m.coff = 0;
-    m.p = c.arena->alloc((size_t)B * H * W * C);
+    m.p = c.act_alloc((size_t)B * H * W * C);      // fp32 map, or bf16 in compute mode BRN_BF16
     return m;
 }
 
@@ -57,8 +57,34 @@ static void fill_epilogue(GemmParams& p, const GemmW& w) {
     p.Wp = w.wp; p.planes = w.planes; p.wp_rows = w.wp_rows;
 }
 
+// bf16-storage mode: the same GEMM on kernels/gemm_bf16.hip (A bf16; C / R bf16 unless flagged fp32)
+static void run_gemm_bf16(Ctx& c, const GemmW& w, GemmParams& p, int fam) {
+    if (!w.wb) fail(BRN_ERR_INVALID_ARG, "bf16 mode: weight without a bf16 copy");
+    const GemmPlan pl = plan_gemm_bf16(p.M, p.N, p.K);
+    const size_t mk = c.arena->mark();
+    float* ws = pl.ws_floats ? c.arena->alloc(pl.ws_floats) : nullptr;
+    c.arena->release(mk);
+    if (c.dry) return;
+    p.Wp = w.wb; p.wp_rows = w.wb_rows; p.wp_ld = w.wb_ld; p.planes = 1;
+    const double flop = 2.0 * p.M * (double)p.N * p.K;
+    const double a_elems = p.mode == GEMM_DENSE ? (double)p.M * p.K : (double)p.M / ((double)p.Hout * p.Wout) * p.Hin * p.Win * p.Cin;
+    const double bytes = 2.0 * (a_elems + (double)p.N * p.K) + (p.c_f32 ? 4.0 : 2.0) * (double)p.M * p.N + (p.R ? (p.r_f32 ? 4.0 : 2.0) * (double)p.M * p.N : 0.0);
+    Bracket b(c, fam, flop, bytes, p.M, p.N, p.K);
+    BRN_LAUNCH(launch_gemm_bf16(p, pl, ws, c.stream));
+}
+
 void run_gemm(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* C, int ldc, int c_coff, const float* R, int ldr,
-              int r_coff, const float* bbias, int bbias_rows, int a_planes, int c_planes) {
+              int r_coff, const float* bbias, int bbias_rows, int a_planes, int c_planes, int c_f32, int r_f32) {
+    if (c.bf16) {
+        GemmParams p{};
+        p.A = A; p.C = C; p.M = M; p.N = w.N; p.K = w.K; p.mode = GEMM_DENSE; p.lda = lda;
+        p.bias = w.bias; p.scale = w.scale; p.shift = w.shift; p.act = w.act;
+        p.bbias = bbias; p.bbias_rows = bbias_rows > 0 ? bbias_rows : 1;
+        p.R = R; p.ldr = ldr; p.r_coff = r_coff; p.ldc = ldc; p.c_coff = c_coff;
+        p.c_f32 = c_f32; p.r_f32 = r_f32;
+        run_gemm_bf16(c, w, p, FAM_GEMM_DENSE);
+        return;
+    }
     GemmPlan pl = plan_gemm(M, w.N, w.K, w.wp ? w.planes : 0);
     if (a_planes || c_planes) {
         // P2 operands exist only on the warp-specialised 2-plane kernel; a P2 output cannot go through the split-K reduce pass
@@ -82,7 +108,7 @@ void run_gemm(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* C, 
     BRN_LAUNCH(launch_gemm(p, pl, ws, c.stream));
 }
 
-void run_conv(Ctx& c, const GemmW& w, const Map& in, const Map& out, const float* om, int om_ld, int om_mask_off) {
+void run_conv(Ctx& c, const GemmW& w, const Map& in, const Map& out, const float* om, int om_ld, int om_mask_off, int c_f32) {
     const int Hout = (in.H + 2 * w.pad - w.dil * (w.kh - 1) - 1) / w.stride + 1;
     const int Wout = (in.W + 2 * w.pad - w.dil * (w.kw - 1) - 1) / w.stride + 1;
     if (out.H != Hout || out.W != Wout || out.B != in.B || out.C != w.N)
@@ -92,10 +118,22 @@ void run_conv(Ctx& c, const GemmW& w, const Map& in, const Map& out, const float
         fail(BRN_ERR_INVALID_ARG, "conv input window (C=%d coff=%d ld=%d) cannot supply %d channels", in.C, in.coff, in.ld, w.Cinp);
     const int M = out.B * Hout * Wout;
     if (w.mode == GEMM_DENSE) {
-        run_gemm(c, w, in.p + in.coff, M, in.ld, out.p, out.ld, out.coff);
+        run_gemm(c, w, c.at(in.p, in.coff), M, in.ld, out.p, out.ld, out.coff, nullptr, 0, 0, nullptr, 0, 0, 0, c_f32);
         return;
     }
-    const GemmPlan pl = plan_gemm(M, w.N, w.K, (w.wp && w.mode == GEMM_CONV_NHWC) ? w.planes : 0);
+    if (c.bf16 && w.mode == GEMM_CONV_NHWC) {
+        GemmParams p{};
+        p.A = in.p; p.C = out.p; p.M = M; p.N = w.N; p.K = w.K; p.mode = GEMM_CONV_NHWC;
+        p.lda = in.ld; p.a_coff = in.coff;
+        p.Hin = in.H; p.Win = in.W; p.Cin = w.Cinp; p.kh = w.kh; p.kw = w.kw; p.stride = w.stride; p.pad = w.pad; p.dil = w.dil;
+        p.Hout = Hout; p.Wout = Wout; p.Kreal = w.Kreal;
+        p.bias = w.bias; p.scale = w.scale; p.shift = w.shift; p.act = w.act;
+        p.bbias_rows = 1; p.ldc = out.ld; p.c_coff = out.coff; p.c_f32 = c_f32;
+        run_gemm_bf16(c, w, p, FAM_GEMM_CONV);
+        return;
+    }
+    GemmPlan pl = plan_gemm(M, w.N, w.K, (w.wp && w.mode == GEMM_CONV_NHWC) ? w.planes : 0);
+    if (c.bf16) { pl.splitk = 1; pl.ws_floats = 0; }     // (the fp32 split-K reduce pass has no bf16 output; deformable convs only)
     const size_t mk = c.arena->mark();
     float* ws = pl.ws_floats ? c.arena->alloc(pl.ws_floats) : nullptr;
     c.arena->release(mk);
@@ -108,6 +146,7 @@ void run_conv(Ctx& c, const GemmW& w, const Map& in, const Map& out, const float
     p.om = om; p.om_ld = om_ld; p.om_mask_off = om_mask_off;
     fill_epilogue(p, w);
     p.bbias_rows = 1; p.ldc = out.ld; p.c_coff = out.coff;
+    if (c.bf16) { p.a_bf16 = 1; p.c_bf16 = c_f32 ? 0 : 1; }   // deformable gather in bf16 mode: bf16 map in / out on the fp32-MFMA kernel
     if (w.mode == GEMM_DEFORM_NHWC && !om) fail(BRN_ERR_INVALID_ARG, "deformable conv without an offset/modulator map");
     const double flop = 2.0 * M * (double)w.N * w.K;
     const double bytes = 4.0 * ((double)in.pixels() * w.Cinp + (double)w.N * w.K + (double)M * w.N);
@@ -138,20 +177,20 @@ void run_conv_nchw(Ctx& c, const GemmW& w, const float* x, int B, int Hin, int W
     BRN_LAUNCH(launch_gemm(p, pl, ws, c.stream));
 }
 
-void run_layernorm(Ctx& c, const LNW& ln, const float* x, int rows, int ldx, float* y, int ldy, int y_coff, int y_planes) {
+void run_layernorm(Ctx& c, const LNW& ln, const float* x, int rows, int ldx, float* y, int ldy, int y_coff, int y_planes, int y_bf16) {
     if (c.dry) return;
     LayerNormParams p{};
     p.x = x; p.y = y; p.rows = rows; p.C = ln.C; p.gamma = ln.g; p.beta = ln.b; p.eps = 1e-5f;
-    p.ldx = ldx; p.ldy = ldy; p.y_coff = y_coff; p.mode = 0; p.y_planes = y_planes;
-    Bracket b(c, FAM_LAYERNORM, 0.0, 8.0 * rows * (double)ln.C);
+    p.ldx = ldx; p.ldy = ldy; p.y_coff = y_coff; p.mode = 0; p.y_planes = y_planes; p.y_bf16 = y_bf16;
+    Bracket b(c, FAM_LAYERNORM, 0.0, (y_bf16 ? 6.0 : 8.0) * rows * (double)ln.C);
     BRN_LAUNCH(launch_layernorm(p, c.stream));
 }
 
 void run_resize(Ctx& c, const Map& in, const Map& out) {
     if (in.C != out.C || in.B != out.B) fail(BRN_ERR_INVALID_ARG, "resize: channel/batch mismatch");
     if (c.dry) return;
-    Bracket b(c, FAM_RESIZE, 0.0, 4.0 * ((double)in.pixels() + (double)out.pixels()) * in.C);
-    BRN_LAUNCH(launch_resize_nhwc(in.p, in.B, in.H, in.W, in.C, in.ld, in.coff, out.p, out.H, out.W, out.ld, out.coff, c.stream));
+    Bracket b(c, FAM_RESIZE, 0.0, (double)c.esz() * ((double)in.pixels() + (double)out.pixels()) * in.C);
+    BRN_LAUNCH(launch_resize_nhwc(in.p, in.B, in.H, in.W, in.C, in.ld, in.coff, out.p, out.H, out.W, out.ld, out.coff, c.stream, c.bf16));
 }
 
 // ---- Swin --------------------------------------------------------------------------------------------------------------
@@ -170,9 +209,9 @@ static void swin_attention_multi(Ctx& c, const SwinBlockW& blk, const float* xn,
     const size_t mk = c.arena->mark();
     int M = 0;
     for (int k = 0; k < nin; ++k) M += B * hs[k] * wsz[k];
-    float* qkv = c.arena->alloc((size_t)M * 3 * C);
+    float* qkv = c.act_alloc((size_t)M * 3 * C);                        // (bf16 in compute mode BRN_BF16, like att and xn)
     const int ldp = p2 ? C * p2 / 2 : C;                                // row stride (floats) of a P-layout [M][C] buffer
-    float* att = c.arena->alloc((size_t)M * ldp);
+    float* att = c.act_alloc((size_t)M * ldp);
     run_gemm(c, blk.qkv, xn, M, ldp, qkv, 3 * C, 0, nullptr, 0, 0, nullptr, 0, p2, 0);   // swin.rs:217 (pad rows are synthesised by the kernel)
     if (!c.dry) {
         // one launch for all maps of the pass (full + half scale): fewer ramps and tails than one launch per geometry
@@ -181,19 +220,21 @@ static void swin_attention_multi(Ctx& c, const SwinBlockW& blk, const float* xn,
         double nwin = 0.0;
         for (int k = 0; k < nin; ++k) {
             WindowAttnParams& p = ps[k];
-            p.qkv = qkv + off * 3 * C; p.qkv_bias = blk.qkv.bias; p.rel_table = blk.rel_table; p.out = att + off * ldp;
+            p.qkv = c.at(qkv, off * 3 * C); p.qkv_bias = blk.qkv.bias; p.rel_table = blk.rel_table; p.out = c.at(att, off * ldp);
+            p.io_bf16 = c.bf16;
             p.B = B; p.H = hs[k]; p.W = wsz[k]; p.C = C; p.heads = blk.heads;
             p.Hp = roundup(hs[k], 12); p.Wp = roundup(wsz[k], 12);   // swin.rs:359-360
             p.shift = shift; p.scale = 1.0f / sqrtf(32.0f);          // head_dim^-0.5 (swin.rs:134)
-            p.planes = (blk.qkv.planes == 2 || blk.qkv.planes == 1) ? blk.qkv.planes : 0;
+            p.planes = (!c.bf16 && (blk.qkv.planes == 2 || blk.qkv.planes == 1)) ? blk.qkv.planes : 0;
             p.out_planes = p2;
             nwin += (double)B * (p.Hp / 12) * (p.Wp / 12) * blk.heads;
             off += (size_t)B * hs[k] * wsz[k];
         }
-        Bracket b(c, FAM_ATTENTION, nwin * 2.0 * 2.0 * 144 * 144 * 32, 4.0 * ((double)M * 4 * C), M, C, shift);
+        Bracket b(c, FAM_ATTENTION, nwin * 2.0 * 2.0 * 144 * 144 * 32, (double)c.esz() * ((double)M * 4 * C), M, C, shift);
         BRN_LAUNCH(launch_window_attention2(ps[0], nin > 1 ? &ps[1] : nullptr, c.stream));
     }
-    run_gemm(c, blk.proj, att, M, ldp, y, C, 0, residual, C, 0, nullptr, 0, p2, 0);      // swin.rs:310 (+ shortcut, swin.rs:406)
+    // swin.rs:310 (+ shortcut, swin.rs:406); the residual stream y / residual stays fp32 in every mode
+    run_gemm(c, blk.proj, att, M, ldp, y, C, 0, residual, C, 0, nullptr, 0, p2, 0, c.bf16, c.bf16);
     c.arena->release(mk);
 }
 
@@ -242,36 +283,38 @@ void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int 
             if (np == 2 && b0.qkv.wp && b0.proj.wp && b0.fc1.wp && b0.fc2.wp && C % 32 == 0 && hidden % 32 == 0) stage_pl = np;
         }
         const int ldx = stage_pl ? C * stage_pl / 2 : C, ldh = stage_pl ? hidden * stage_pl / 2 : hidden;
-        float* xn = c.arena->alloc((size_t)M * ldx);
-        float* hid = c.arena->alloc((size_t)M * ldh);
+        // compute mode BRN_BF16: x (the residual stream) stays fp32; every GEMM operand (xn, qkv, att, hid, pm) is bf16
+        const int yb = c.bf16;
+        float* xn = c.act_alloc((size_t)M * ldx);
+        float* hid = c.act_alloc((size_t)M * ldh);
         for (size_t j = 0; j < st.blocks.size(); ++j) {
             const SwinBlockW& bk = st.blocks[j];
             const int shift = (j % 2 == 0) ? 0 : w.window / 2;                       // swin.rs:552
             // split modes: every GEMM input of the block is written by its producer in the P layout (the bf16 planes the GEMM
             // would split out while staging), so the GEMMs' staging waves only copy
             const int p2 = stage_pl;
-            run_layernorm(c, bk.norm1, x, M, C, xn, ldx, 0, p2);                      // swin.rs:355
+            run_layernorm(c, bk.norm1, x, M, C, xn, ldx, 0, p2, yb);                  // swin.rs:355
             swin_attention_multi(c, bk, xn, B, nin, hh, ww, C, shift, x, x, p2);      // x = shortcut + attn (swin.rs:406)
-            run_layernorm(c, bk.norm2, x, M, C, xn, ldx, 0, p2);                      // swin.rs:407
+            run_layernorm(c, bk.norm2, x, M, C, xn, ldx, 0, p2, yb);                  // swin.rs:407
             run_gemm(c, bk.fc1, xn, M, ldx, hid, ldh, 0, nullptr, 0, 0, nullptr, 0, p2, p2);   // fc1 + gelu_erf (swin.rs:104-105)
-            run_gemm(c, bk.fc2, hid, M, ldh, x, C, 0, x, C, 0, nullptr, 0, p2, 0);     // x + fc2(...) (swin.rs:106,407)
+            run_gemm(c, bk.fc2, hid, M, ldh, x, C, 0, x, C, 0, nullptr, 0, p2, 0, yb, yb);     // x + fc2(...) (swin.rs:106,407)
         }
         // stage output = norm_i(x_out), pre-downsample (swin.rs:591,784-789); written into its consumer's window
         size_t off = 0, off2 = 0;
         float* pm = nullptr;
         const int pm_pl = (st.has_down && st.reduction.wp && st.reduction.planes == 2 && (4 * C) % 32 == 0) ? 2 : 0;
         const int ldpm = pm_pl ? 4 * C * pm_pl / 2 : 4 * C;
-        if (st.has_down) pm = c.arena->alloc((size_t)total(i + 1) * ldpm);
+        if (st.has_down) pm = c.act_alloc((size_t)total(i + 1) * ldpm);
         for (int k = 0; k < nin; ++k) {
             const Map& o = ins[k].outs[i];
             if (o.B != B || o.H != hh[k] || o.W != ww[k] || o.C != C) fail(BRN_ERR_INVALID_ARG, "swin output window %d has the wrong shape", i);
-            run_layernorm(c, st.out_norm, x + off * C, rows(k, i), C, o.p, o.ld, o.coff);
+            run_layernorm(c, st.out_norm, x + off * C, rows(k, i), C, o.p, o.ld, o.coff, 0, yb);
             if (st.has_down) {
                 // PatchMerging (swin.rs:491-527): gather 2x2 + LN(4C) fused, then the bias-free reduction (below, once)
                 const int M2 = rows(k, i + 1);
                 if (!c.dry) {
                     LayerNormParams p{};
-                    p.x = x + off * C; p.y = pm + off2 * ldpm; p.rows = M2; p.C = 4 * C; p.gamma = st.down_norm.g; p.beta = st.down_norm.b;
+                    p.x = x + off * C; p.y = c.at(pm, off2 * ldpm); p.rows = M2; p.y_bf16 = yb; p.C = 4 * C; p.gamma = st.down_norm.g; p.beta = st.down_norm.b;
                     p.eps = 1e-5f; p.ldy = ldpm; p.y_coff = 0; p.mode = 1; p.H = hh[k]; p.W = ww[k]; p.Cin = C;
                     p.y_planes = pm_pl;                                            // P layout for the reduction GEMM
                     Bracket b(c, FAM_LAYERNORM, 0.0, 8.0 * M2 * 4.0 * C);
@@ -281,7 +324,7 @@ void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int 
             }
             off += rows(k, i);
         }
-        if (st.has_down) run_gemm(c, st.reduction, pm, total(i + 1), ldpm, xnext, 2 * C, 0, nullptr, 0, 0, nullptr, 0, pm_pl, 0);
+        if (st.has_down) run_gemm(c, st.reduction, pm, total(i + 1), ldpm, xnext, 2 * C, 0, nullptr, 0, 0, nullptr, 0, pm_pl, 0, yb, 0);
         c.arena->release(mk);
         x = xnext;
     }
@@ -311,8 +354,8 @@ void decblk_forward(Ctx& c, const DecBlkW& w, const Map& in, const Map& out, int
             const int kk = d.k * d.k, ldom = roundup(3 * kk, 4);
             const size_t mk2 = c.arena->mark();
             Map om; om.B = B; om.H = H; om.W = W; om.C = 3 * kk; om.ld = ldom; om.coff = 0;
-            om.p = c.arena->alloc((size_t)M * ldom);
-            run_conv(c, d.offmod, t, om);                            // offset_conv | modulator_conv (aspp.rs:171,173)
+            om.p = c.arena->alloc((size_t)M * ldom);                 // offsets / modulator stay fp32 in every mode
+            run_conv(c, d.offmod, t, om, nullptr, 0, 0, 1);          // offset_conv | modulator_conv (aspp.rs:171,173)
             if (!c.dry) {
                 Bracket b(c, FAM_ELEMENTWISE, 0.0, 8.0 * M * kk);
                 BRN_LAUNCH(launch_mod_sigmoid2(om.p, (size_t)M, ldom, 2 * kk, 3 * kk, c.stream));   // 2*sigmoid (aspp.rs:174)
@@ -328,7 +371,7 @@ void decblk_forward(Ctx& c, const DecBlkW& w, const Map& in, const Map& out, int
     float* gscr = c.arena->alloc(gap_scratch_floats(B, H * W, 64));
     if (!c.dry) {
         Bracket b(c, FAM_ELEMENTWISE, 0.0, 4.0 * M * 64);
-        BRN_LAUNCH(launch_gap_nhwc(t.p, B, H * W, 64, 64, 0, gscr, g0, c.stream));
+        BRN_LAUNCH(launch_gap_nhwc(t.p, B, H * W, 64, 64, 0, gscr, g0, c.stream, c.bf16));
         BRN_LAUNCH(launch_small_fc(g0, B, 64, a.gap_w, 64, 0, 256, a.gap_scale, a.gap_shift, ACT_RELU, g1, c.stream));
         BRN_LAUNCH(launch_small_fc(g1, B, 256, a.conv1_full, 1280, 1024, 64, nullptr, nullptr, ACT_NONE, gb, c.stream));
     }
@@ -346,7 +389,7 @@ static void ipt_block(Ctx& c, const SimpleConvsW& w, const float* img, int B, in
     Map pt = new_map(c, B, th, tw, cinp);
     if (!c.dry) {
         Bracket b(c, FAM_ELEMENTWISE, 0.0, 8.0 * B * 3.0 * H * W);
-        BRN_LAUNCH(launch_image2patches(img, B, 3, H, W, th, tw, pt.p, cinp, cinp, c.stream));   // birefnet.rs:288-300
+        BRN_LAUNCH(launch_image2patches(img, B, 3, H, W, th, tw, pt.p, cinp, cinp, c.stream, c.bf16));   // birefnet.rs:288-300
     }
     Map mid = new_map(c, B, th, tw, 64);
     run_conv(c, w.conv1, pt, mid);        // no activation between the two convs (decoder.rs:52)
@@ -360,7 +403,7 @@ static void gdt_gate(Ctx& c, const DecoderW& d, int i, const Map& p) {
     run_conv(c, d.gdt[i], p, g);                                      // conv3x3 -> 16, BN, ReLU (birefnet.rs:111-117)
     if (!c.dry) {
         Bracket b(c, FAM_ELEMENTWISE, 0.0, 8.0 * p.pixels() * p.C);
-        BRN_LAUNCH(launch_gdt_gate(p.p, (int)p.pixels(), p.C, p.ld, p.coff, g.p, 16, d.gdt_attn_w[i], d.gdt_attn_b[i], c.stream));
+        BRN_LAUNCH(launch_gdt_gate(p.p, (int)p.pixels(), p.C, p.ld, p.coff, g.p, 16, d.gdt_attn_w[i], d.gdt_attn_b[i], c.stream, c.bf16));
     }
     c.arena->release(mk);
 }
@@ -379,7 +422,7 @@ void decoder_forward(Ctx& c, const Model& m, const float* img, int B, int H, int
     // stage 3 (birefnet.rs:332-344); ipt4_up is a same-size resize = identity
     Map d3 = new_map(c, B, h3, w3, 1920);
     run_resize(c, p4, d3.window(0, 1536));
-    run_gemm(c, d.lat[0], x3.p + x3.coff, B * h3 * w3, x3.ld, d3.p, d3.ld, 0, d3.p, d3.ld, 0);   // + lateral_block4(x3)
+    run_gemm(c, d.lat[0], c.at(x3.p, x3.coff), B * h3 * w3, x3.ld, d3.p, d3.ld, 0, d3.p, d3.ld, 0);   // + lateral_block4(x3)
     ipt_block(c, d.ipt[3], img, B, H, W, h3, w3, 768, d3.window(1536, 384));
     Map p3 = new_map(c, B, h3, w3, 768);
     decblk_forward(c, d.dec[1], d3, p3, dm);
@@ -387,7 +430,7 @@ void decoder_forward(Ctx& c, const Model& m, const float* img, int B, int H, int
     // stage 2 (birefnet.rs:347-359)
     Map d2 = new_map(c, B, h2, w2, 960);
     run_resize(c, p3, d2.window(0, 768));
-    run_gemm(c, d.lat[1], x2.p + x2.coff, B * h2 * w2, x2.ld, d2.p, d2.ld, 0, d2.p, d2.ld, 0);
+    run_gemm(c, d.lat[1], c.at(x2.p, x2.coff), B * h2 * w2, x2.ld, d2.p, d2.ld, 0, d2.p, d2.ld, 0);
     ipt_block(c, d.ipt[2], img, B, H, W, h2, w2, 192, d2.window(768, 192));
     Map p2 = new_map(c, B, h2, w2, 384);
     decblk_forward(c, d.dec[2], d2, p2, dm);
@@ -395,7 +438,7 @@ void decoder_forward(Ctx& c, const Model& m, const float* img, int B, int H, int
     // stage 1 (birefnet.rs:362-369)
     Map d1 = new_map(c, B, h1, w1, 480);
     run_resize(c, p2, d1.window(0, 384));
-    run_gemm(c, d.lat[2], x1.p + x1.coff, B * h1 * w1, x1.ld, d1.p, d1.ld, 0, d1.p, d1.ld, 0);
+    run_gemm(c, d.lat[2], c.at(x1.p, x1.coff), B * h1 * w1, x1.ld, d1.p, d1.ld, 0, d1.p, d1.ld, 0);
     ipt_block(c, d.ipt[1], img, B, H, W, h1, w1, 48, d1.window(384, 96));
     Map p1 = new_map(c, B, h1, w1, 192);
     decblk_forward(c, d.dec[3], d1, p1, dm);
@@ -405,7 +448,7 @@ void decoder_forward(Ctx& c, const Model& m, const float* img, int B, int H, int
     float* tl = c.arena->alloc((size_t)B * H * W);
     if (!c.dry) {
         Bracket b(c, FAM_ELEMENTWISE, 2.0 * B * H * (double)W * 75, 4.0 * B * H * (double)W * 5);
-        BRN_LAUNCH(launch_pixel_dot(p1.p, B * h1 * w1, 192, p1.ld, p1.coff, d.out_w, 0.f, q, c.stream));
+        BRN_LAUNCH(launch_pixel_dot(p1.p, B * h1 * w1, 192, p1.ld, p1.coff, d.out_w, 0.f, q, c.stream, c.bf16));
         BRN_LAUNCH(launch_head_stencil5x5(img, B, H, W, d.head_k, d.head_b, tl, c.stream));
         BRN_LAUNCH(launch_final_head(q, B, h1, w1, tl, d.out_b, H, W, apply_sigmoid, out, c.stream));
     }
@@ -464,6 +507,7 @@ Model::~Model() {
     if (arena.base) (void)hipFree(arena.base);
     for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
     if (stage_ev_ok) for (int i = 0; i < 6; ++i) (void)hipEventDestroy(stage_ev[i]);
+    if (done_ev) (void)hipEventDestroy(done_ev);
 }
 
 }  // namespace brn

@@ -9,6 +9,7 @@
 #include <unordered_map>
 #include <stdexcept>
 #include <mutex>
+#include <type_traits>
 #include "../../include/birefnet_hip.h"
 #include "brn_kernels.h"
 
@@ -42,6 +43,7 @@ struct Arena {
     size_t cap = 0, top = 0, peak = 0;
     bool dry = false;
     float* alloc(size_t nfloats);
+    float* alloc_bytes(size_t bytes) { return alloc((bytes + 3) / 4); }
     size_t mark() const { return top; }
     void release(size_t m) { top = m; }
 };
@@ -53,6 +55,11 @@ struct Ctx {
     bool profile;                   // bracket every launch with events
     std::vector<LaunchRecord>* records;
     std::vector<hipEvent_t>* event_pool; size_t* event_next;
+    // compute mode BRN_BF16: activation maps are bf16 in HBM (esz = 2); pointers stay typed float* and are opaque to the host
+    bool bf16 = false;
+    int esz() const { return bf16 ? 2 : 4; }
+    float* act_alloc(size_t elems) { return arena->alloc_bytes(elems * (size_t)esz()); }
+    template <class T> T* at(T* p, size_t elems) const { return reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(p)) + elems * (size_t)esz()); }
 };
 
 // channels-last window view: logical [B,H,W,C] living in columns [coff, coff+C) of rows that are ld floats wide
@@ -71,6 +78,8 @@ struct GemmW {          // one Linear / Conv2d, repacked for gemm_f32
     float* w = nullptr; // [roundup(N,128)][K]
     void* wp = nullptr; // split-bf16 path: [planes][roundup(N,128)][K] bf16 planes of the same matrix (or null)
     int planes = 0, wp_rows = 0;
+    void* wb = nullptr; // bf16-storage mode (BRN_BF16): plain [wb_rows][wb_ld] bf16, rows padded to 256, K padded to 64 (zeros)
+    int wb_rows = 0, wb_ld = 0;
     int N = 0, K = 0, Kreal = 0;
     int Cin = 0, Cinp = 0, kh = 1, kw = 1, stride = 1, pad = 0, dil = 1;
     int mode = GEMM_DENSE;
@@ -162,7 +171,11 @@ struct Model {
     Arena arena;
     int plan_B = 0, plan_H = 0, plan_W = 0;
     std::mutex mu;            // forward calls on one handle are serialised (one workspace)
+    // the workspace is reused by every forward: a call on a different stream than the previous one first waits (on the GPU)
+    // for the previous forward's last kernel, so two streams never overlap inside the arena
+    hipEvent_t done_ev = nullptr; hipStream_t last_stream = nullptr; bool has_last = false;
     bool profiling = false;
+    bool bf16 = false;        // BRN_BF16: bf16 activations / weights in HBM
     std::vector<LaunchRecord> records;
     std::vector<hipEvent_t> event_pool; size_t event_next = 0;
     hipEvent_t stage_ev[6]; bool stage_ev_ok = false;
@@ -188,10 +201,12 @@ void fold_bn(DeviceOwner& own, GemmW& g, const float* conv_bias_host, const floa
 // ---- graph pieces ------------------------------------------------------------------------------------------------
 void run_gemm(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* C, int ldc, int c_coff,
               const float* R = nullptr, int ldr = 0, int r_coff = 0, const float* bbias = nullptr, int bbias_rows = 1,
-              int a_planes = 0, int c_planes = 0 /* 2: operand in the P2 layout (kernels/split_planes.h) */);
-void run_conv(Ctx& c, const GemmW& w, const Map& in, const Map& out, const float* om = nullptr, int om_ld = 0, int om_mask_off = 0);
+              int a_planes = 0, int c_planes = 0 /* 2: operand in the P2 layout (kernels/split_planes.h) */,
+              int c_f32 = 0, int r_f32 = 0 /* compute mode BRN_BF16 only: C written / R read as fp32 (the residual stream) */);
+void run_conv(Ctx& c, const GemmW& w, const Map& in, const Map& out, const float* om = nullptr, int om_ld = 0, int om_mask_off = 0,
+              int c_f32 = 0);
 void run_conv_nchw(Ctx& c, const GemmW& w, const float* x_nchw, int B, int Hin, int Win, const Map& out);
-void run_layernorm(Ctx& c, const LNW& ln, const float* x, int rows, int ldx, float* y, int ldy, int y_coff, int y_planes = 0);
+void run_layernorm(Ctx& c, const LNW& ln, const float* x, int rows, int ldx, float* y, int ldy, int y_coff, int y_planes = 0, int y_bf16 = 0);
 void run_resize(Ctx& c, const Map& in, const Map& out);
 
 // SwinTransformer::forward (swin.rs:768-797): outs[i] are destination windows (stage outputs after norm_i)
@@ -209,7 +224,9 @@ void decoder_forward(Ctx& c, const Model& m, const float* img_nchw, int B, int H
 void model_forward(Model& m, Ctx& c, const float* img_nchw, int B, int H, int W, float* out, int apply_sigmoid);
 
 void ensure_device(int ordinal);
-// number of bf16 planes the weight builders attach to every dense / channels-last conv GemmW (0 = fp32 MFMA path only)
+// number of bf16 planes the weight builders attach to every dense / channels-last conv GemmW (0 = fp32 MFMA path only);
+// BUILD_BF16: attach the plain bf16 matrix of the bf16-storage mode instead
+constexpr int BUILD_BF16 = 16;
 void set_build_planes(int planes);
 int build_planes();
 

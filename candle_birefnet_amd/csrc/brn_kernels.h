@@ -42,6 +42,10 @@ struct GemmParams {
     // split-K (filled by launch_gemm from the plan): slices write raw partials to part[slice][M][N]
     int splitk; float* part;
     int a_planes, c_planes;   // 2: A is read / C is written in the P2 layout (kernels/split_planes.h); split-bf16 dense ws kernel only
+    // bf16-storage mode (kernels/gemm_bf16.hip): A, C, R are bf16 unless flagged; Wp is the plain [wp_rows][wp_ld] bf16 matrix
+    int wp_ld;                // elements per W row (K rounded up to 64, zero padded)
+    int c_f32, r_f32;         // 1: C is written / R is read as fp32 (offset maps of the deformable mode, fp32 side outputs)
+    int a_bf16, c_bf16;       // gemm_f32_kernel only (deformable gather in bf16 mode): A map read / C written as bf16
     unsigned long long* trace;   // diagnostics only: per-workgroup cycle stamps (gemm_split_ws_kernel), null in production
     int abl;   // diagnostics only (brn_gemm_microbench): 1 = no global loads in the K loop, 2 = no LDS staging, 4 = no fragment reads / MFMA
 };
@@ -51,10 +55,16 @@ GemmPlan plan_gemm(int M, int N, int K, int planes = 0);   // planes: bf16 plane
 // ws: plan.ws_floats floats of scratch when plan.splitk > 1.  Returns the hipError_t of the launch(es).
 hipError_t launch_gemm(const GemmParams& p, const GemmPlan& plan, float* ws, hipStream_t s);
 
+// bf16-storage mode: plan + launch (kernels/gemm_bf16.hip).  cfg: 0 / 2 = 128x128, 1 / 3 = 128x64 block tile (K step 64 / 32)
+GemmPlan plan_gemm_bf16(int M, int N, int K);
+hipError_t launch_gemm_bf16(const GemmParams& p, const GemmPlan& plan, float* ws, hipStream_t s);
+
+#ifdef BRN_DIAG_BUILD
 hipError_t launch_mfma_valu_probe(int blocks, int iters, int mode, float* sink, hipStream_t s);
 hipError_t launch_lds_mfma_probe(int blocks, int iters, int np, int variant, float* sink, hipStream_t s);
 hipError_t launch_mfma_peak_bf16(int blocks, int iters, float* sink, unsigned long long* clk, int nacc, hipStream_t s);
 hipError_t launch_mfma_peak(int blocks, int iters, float* sink, unsigned long long* clk, hipStream_t s);
+#endif
 
 struct LayerNormParams {
     const float* x; float* y;
@@ -66,6 +76,7 @@ struct LayerNormParams {
     // (2i,2j),(2i+1,2j),(2i,2j+1),(2i+1,2j+1) of x [B,H,W,Cin], zero outside (odd H/W padding), C == 4*Cin
     int mode; int H, W, Cin;
     int y_planes;         // 2: write y in the P2 layout (kernels/split_planes.h) for a split-bf16 GEMM; 0: fp32
+    int y_bf16;           // 1: y is a bf16 matrix (compute mode BRN_BF16; x stays fp32: the residual stream)
 };
 hipError_t launch_layernorm(const LayerNormParams& p, hipStream_t s);
 
@@ -80,6 +91,7 @@ struct WindowAttnParams {
     float scale;          // head_dim^-0.5
     int planes;           // 0: fp32 MFMA kernel (modes f32, f32_split3); 2 / 1: bf16-split kernel (f32_split2 / bf16_operands)
     int out_planes;       // 2: write `out` in the P2 layout (kernels/split_planes.h) for the proj GEMM; 0: fp32
+    int io_bf16;          // 1: qkv and out are bf16 matrices (compute mode BRN_BF16; qkv_bias / rel_table stay fp32)
 };
 hipError_t launch_window_attention(const WindowAttnParams& p, hipStream_t s);
 // two maps of the same stage in one launch (p2 may be null)
@@ -88,27 +100,30 @@ hipError_t launch_window_attention2(const WindowAttnParams& p, const WindowAttnP
 // ---- data movement / elementwise (HBM-bound) ------------------------------------------------------------
 // bilinear, align_corners=true, channels-last window -> window; optional accumulate (y += )
 hipError_t launch_resize_nhwc(const float* x, int B, int Hin, int Win, int C, int ldx, int x_coff,
-                              float* y, int Hout, int Wout, int ldy, int y_coff, hipStream_t s);
+                              float* y, int Hout, int Wout, int ldy, int y_coff, hipStream_t s, int bf16 = 0);
 // NCHW planar bilinear (the 3-channel image -> half scale), align_corners=true
 hipError_t launch_resize_nchw(const float* x, int BC, int Hin, int Win, float* y, int Hout, int Wout, hipStream_t s);
 // NCHW -> NHWC window and back
-hipError_t launch_nchw_to_nhwc(const float* x, int B, int C, int H, int W, float* y, int ldy, int y_coff, hipStream_t s);
-hipError_t launch_nhwc_to_nchw(const float* x, int B, int C, int H, int W, int ldx, int x_coff, float* y, hipStream_t s);
+// (bf16 = 1: the channels-last side is a bf16 map, ld / coff in elements; the NCHW side is always fp32)
+hipError_t launch_nchw_to_nhwc(const float* x, int B, int C, int H, int W, float* y, int ldy, int y_coff, hipStream_t s, int bf16 = 0);
+hipError_t launch_nhwc_to_nchw(const float* x, int B, int C, int H, int W, int ldx, int x_coff, float* y, hipStream_t s, int bf16 = 0);
 // image2patches (birefnet.rs:288-300): x NCHW [B,Cimg,H,W] -> y[b, th, tw, (c,gh,gw)] channels-last, ld = ldy
 hipError_t launch_image2patches(const float* x, int B, int Cimg, int H, int W, int th, int tw,
-                                float* y, int ldy, int cpad, hipStream_t s);
+                                float* y, int ldy, int cpad, hipStream_t s, int bf16 = 0);
 // per-(b,c) mean over H*W of a channels-last window: out[b][c]   (aspp.rs:314)
 size_t gap_scratch_floats(int B, int HW, int C);
-hipError_t launch_gap_nhwc(const float* x, int B, int HW, int C, int ldx, int x_coff, float* scratch, float* out, hipStream_t s);
+hipError_t launch_gap_nhwc(const float* x, int B, int HW, int C, int ldx, int x_coff, float* scratch, float* out, hipStream_t s, int bf16 = 0);
 // tiny dense layers on [B,Cin] vectors: y[b][n] = act((sum_k x[b][k] w[n*ldw + w_off + k]) * scale[n] + shift[n])
 hipError_t launch_small_fc(const float* x, int B, int Cin, const float* w, int ldw, int w_off, int N,
                            const float* scale, const float* shift, int act, float* y, hipStream_t s);
 // GDT gate (birefnet.rs:327-329): a = sigmoid(dot(g[pix][0:16], w) + b); p[pix][0:C] *= a
 hipError_t launch_gdt_gate(float* p, int npix, int C, int ldp, int p_coff, const float* g, int ldg,
-                           const float* w, float bias, hipStream_t s);
+                           const float* w, float bias, hipStream_t s, int bf16 = 0);
 // per-pixel dot: y[pix] = dot(x[pix][0:C], w) (+ bias)
 hipError_t launch_pixel_dot(const float* x, int npix, int C, int ldx, int x_coff, const float* w, float bias,
-                            float* y, hipStream_t s);
+                            float* y, hipStream_t s, int bf16 = 0);
+// contiguous fp32 -> bf16 (round to nearest even)
+hipError_t launch_f32_to_bf16(const float* x, size_t n, float* y_bf16, hipStream_t s);
 // final head (birefnet.rs:372-375 with conv_out1 commuted through the bilinear upsample):
 // out[b][oy][ox] = bilinear(q [B,h,w] -> H,W) + t[b][oy][ox] (+bias); optional sigmoid
 hipError_t launch_final_head(const float* q, int B, int h, int w, const float* t, float bias, int H, int W,

@@ -10,6 +10,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cstring>
 #include <map>
 
@@ -41,7 +42,10 @@ struct Cursor {
     long long num() {
         ws();
         long long v = 0; bool any = false;
-        while (p < e && *p >= '0' && *p <= '9') { v = v * 10 + (*p - '0'); ++p; any = true; }
+        while (p < e && *p >= '0' && *p <= '9') {
+            if (v > (1LL << 53) / 10) fail(BRN_ERR_INVALID_ARG, "safetensors header: number out of range");   // sizes beyond 2^53 are not a file
+            v = v * 10 + (*p - '0'); ++p; any = true;
+        }
         if (!any) fail(BRN_ERR_INVALID_ARG, "safetensors header: expected a number");
         return v;
     }
@@ -49,15 +53,18 @@ struct Cursor {
         ws();
         if (p >= e) fail(BRN_ERR_INVALID_ARG, "safetensors header: truncated");
         if (*p == '"') { (void)str(); return; }
-        if (*p == '{' || *p == '[') {
-            const char open = *p, close = open == '{' ? '}' : ']';
-            ++p;
-            int depth = 1;
-            while (p < e && depth) {
+        if (*p == '{' || *p == '[') {       // nested containers of either kind, brackets matched on a stack
+            std::vector<char> stack;
+            do {
                 if (*p == '"') { (void)str(); continue; }
-                if (*p == open) ++depth; else if (*p == close) --depth;
+                if (*p == '{' || *p == '[') stack.push_back(*p == '{' ? '}' : ']');
+                else if (*p == '}' || *p == ']') {
+                    if (stack.back() != *p) fail(BRN_ERR_INVALID_ARG, "safetensors header: mismatched brackets");
+                    stack.pop_back();
+                }
                 ++p;
-            }
+            } while (p < e && !stack.empty());
+            if (!stack.empty()) fail(BRN_ERR_INVALID_ARG, "safetensors header: truncated");
             return;
         }
         while (p < e && *p != ',' && *p != '}' && *p != ']') ++p;
@@ -97,11 +104,18 @@ void SafetensorsFile::open(const char* path) {
     const char* data = reinterpret_cast<const char*>(b) + 8 + hl;
     const size_t data_len = map_len - 8 - (size_t)hl;
     Cursor c{reinterpret_cast<const char*>(b) + 8, reinterpret_cast<const char*>(b) + 8 + hl};
+    auto trailer = [&] {      // after the closing brace only padding (spaces, as the safetensors writers emit) may follow
+        c.ws();
+        if (c.p != c.e) fail(BRN_ERR_INVALID_ARG, "'%s': bytes after the header's JSON object", path);
+    };
+    std::map<std::string, int> seen;
+    std::vector<std::pair<long long, long long>> spans;     // [b0, b1) of every tensor, for the overlap check
     c.need('{');
-    if (c.eat('}')) return;
+    if (c.eat('}')) { trailer(); return; }
     do {
         const std::string name = c.str();
         c.need(':');
+        if (seen[name]++) fail(BRN_ERR_INVALID_ARG, "'%s': tensor name '%s' appears twice", path, name.c_str());
         if (name == "__metadata__") { c.skip_value(); continue; }
         std::string dtype; std::vector<int64_t> shape; long long b0 = -1, b1 = -1;
         c.need('{');
@@ -117,10 +131,14 @@ void SafetensorsFile::open(const char* path) {
         } while (c.eat(','));
         c.need('}');
         if (b0 < 0 || b1 < b0 || (size_t)b1 > data_len) fail(BRN_ERR_INVALID_ARG, "'%s': tensor '%s' has data_offsets outside the file", path, name.c_str());
-        size_t numel = 1;
-        for (int64_t d : shape) numel *= (size_t)d;
+        if (b1 > b0) spans.emplace_back(b0, b1);
         const size_t esz = dtype == "F32" ? 4 : (dtype == "F16" || dtype == "BF16") ? 2 : 0;
         if (!esz) continue;                                  // integer / f64 tensors: nothing on this path reads them
+        size_t numel = 1;
+        for (int64_t d : shape) {                            // checked product: a wrapped shape must not pass the size test below
+            if (d < 0 || (d > 0 && numel > (SIZE_MAX / esz) / (size_t)d)) fail(BRN_ERR_SHAPE, "'%s': tensor '%s' has an impossible shape", path, name.c_str());
+            numel *= (size_t)d;
+        }
         if (numel * esz != (size_t)(b1 - b0)) fail(BRN_ERR_SHAPE, "'%s': tensor '%s' byte size does not match its shape", path, name.c_str());
         Entry en;
         en.name = name; en.shape = shape;
@@ -142,6 +160,11 @@ void SafetensorsFile::open(const char* path) {
         }
         entries.push_back(std::move(en));
     } while (c.eat(','));
+    c.need('}');
+    trailer();
+    std::sort(spans.begin(), spans.end());                   // the safetensors crate rejects overlapping tensors; so do we
+    for (size_t i = 1; i < spans.size(); ++i)
+        if (spans[i].first < spans[i - 1].second) fail(BRN_ERR_INVALID_ARG, "'%s': tensors overlap in the data section", path);
 }
 
 std::vector<brn_named_tensor> SafetensorsFile::named(const char* prefix) const {

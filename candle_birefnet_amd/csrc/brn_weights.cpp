@@ -90,6 +90,21 @@ static inline float bf16_to_f32(uint16_t h) {
 static void attach_planes(DeviceOwner& own, GemmW& g, const std::vector<float>& pk, int rows) {
     const int np = g_build_planes;
     if (np <= 0) return;
+    if (np == BUILD_BF16) {      // bf16-storage mode: W = RNE bf16 of the packed matrix, rows padded to 256, K to 64 (gemm_bf16.hip)
+        const size_t K = (size_t)g.K, ld = (K + 63) / 64 * 64;
+        const size_t nrows = pk.size() / K, prow = (nrows + 255) / 256 * 256;
+        std::vector<uint16_t> wb(prow * ld, 0);
+        for (size_t r = 0; r < nrows; ++r)
+            for (size_t k = 0; k < K; ++k) wb[r * ld + k] = bf16_rne(pk[r * K + k]);
+        void* d = nullptr;
+        hipError_t e = hipMalloc(&d, wb.size() * 2 + 16);
+        if (e != hipSuccess) fail(BRN_ERR_OOM, "hipMalloc of %zu bytes failed: %s", wb.size() * 2, hipGetErrorString(e));
+        own.ptrs.push_back(d);
+        BRN_HIP(hipMemcpy(d, wb.data(), wb.size() * 2, hipMemcpyHostToDevice));
+        g.wb = d; g.wb_rows = (int)prow; g.wb_ld = (int)ld;
+        (void)rows;
+        return;
+    }
     const size_t n = pk.size();
     const size_t K = (size_t)g.K;
     std::vector<uint16_t> planes(n * np);

@@ -5,6 +5,24 @@
 namespace brn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4_e __attribute__((ext_vector_type(4)));
+
+// activation element access for both storage types: T = float (fp32 modes) or __bf16 (compute mode BRN_BF16); arithmetic is fp32
+template <class T> __device__ __forceinline__ f32x4 ld4(const T* p);
+template <> __device__ __forceinline__ f32x4 ld4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ f32x4 ld4<__bf16>(const __bf16* p) {
+    const bf16x4_e h = *reinterpret_cast<const bf16x4_e*>(p);
+    f32x4 r = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    return r;
+}
+template <class T> __device__ __forceinline__ void st4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void st4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <> __device__ __forceinline__ void st4<__bf16>(__bf16* p, f32x4 v) {
+    bf16x4_e h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
+    *reinterpret_cast<bf16x4_e*>(p) = h;
+}
 
 static inline dim3 grid1d(size_t n, int block) {
     size_t g = (n + block - 1) / block;
@@ -24,8 +42,9 @@ __device__ __forceinline__ void ac_coord(int dst, int in, int out, int& i0, int&
 }
 
 // Tensor::upsample_bilinear2d(h, w, true) on a channels-last window (birefnet.rs:332,347,362,435-438,450-452)
-__global__ void resize_nhwc_kernel(const float* __restrict__ x, int B, int Hin, int Win, int C4, int ldx, int x_coff,
-                                   float* __restrict__ y, int Hout, int Wout, int ldy, int y_coff) {
+template <class T>
+__global__ void resize_nhwc_kernel(const T* __restrict__ x, int B, int Hin, int Win, int C4, int ldx, int x_coff,
+                                   T* __restrict__ y, int Hout, int Wout, int ldy, int y_coff) {
     const size_t total = (size_t)B * Hout * Wout * C4;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int c4 = (int)(idx % C4);
@@ -36,24 +55,26 @@ __global__ void resize_nhwc_kernel(const float* __restrict__ x, int B, int Hin, 
         int y0, y1, x0, x1; float ly, lx;
         ac_coord(oy, Hin, Hout, y0, y1, ly);
         ac_coord(ox, Win, Wout, x0, x1, lx);
-        const float* base = x + (size_t)b * Hin * Win * ldx + x_coff + c4 * 4;
-        const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * Win + x0) * ldx);
-        const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * Win + x1) * ldx);
-        const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * Win + x0) * ldx);
-        const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * Win + x1) * ldx);
+        const T* base = x + (size_t)b * Hin * Win * ldx + x_coff + c4 * 4;
+        const f32x4 v00 = ld4<T>(base + ((size_t)y0 * Win + x0) * ldx);
+        const f32x4 v01 = ld4<T>(base + ((size_t)y0 * Win + x1) * ldx);
+        const f32x4 v10 = ld4<T>(base + ((size_t)y1 * Win + x0) * ldx);
+        const f32x4 v11 = ld4<T>(base + ((size_t)y1 * Win + x1) * ldx);
         const f32x4 top = v00 + (v01 - v00) * lx;
         const f32x4 bot = v10 + (v11 - v10) * lx;
         const f32x4 r = top + (bot - top) * ly;
-        *reinterpret_cast<f32x4*>(y + (((size_t)b * Hout + oy) * Wout + ox) * ldy + y_coff + c4 * 4) = r;
+        st4<T>(y + (((size_t)b * Hout + oy) * Wout + ox) * ldy + y_coff + c4 * 4, r);
     }
 }
 
 hipError_t launch_resize_nhwc(const float* x, int B, int Hin, int Win, int C, int ldx, int x_coff,
-                              float* y, int Hout, int Wout, int ldy, int y_coff, hipStream_t s) {
+                              float* y, int Hout, int Wout, int ldy, int y_coff, hipStream_t s, int bf16) {
     if (C % 4 || ldx % 4 || ldy % 4 || x_coff % 4 || y_coff % 4) return hipErrorInvalidValue;
     const size_t total = (size_t)B * Hout * Wout * (C / 4);
-    hipLaunchKernelGGL(resize_nhwc_kernel, grid1d(total, 256), dim3(256), 0, s, x, B, Hin, Win, C / 4, ldx, x_coff,
-                       y, Hout, Wout, ldy, y_coff);
+    if (bf16) hipLaunchKernelGGL(resize_nhwc_kernel<__bf16>, grid1d(total, 256), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x), B, Hin, Win, C / 4,
+                                 ldx, x_coff, reinterpret_cast<__bf16*>(y), Hout, Wout, ldy, y_coff);
+    else hipLaunchKernelGGL(resize_nhwc_kernel<float>, grid1d(total, 256), dim3(256), 0, s, x, B, Hin, Win, C / 4, ldx, x_coff,
+                            y, Hout, Wout, ldy, y_coff);
     return hipGetLastError();
 }
 
@@ -83,7 +104,8 @@ hipError_t launch_resize_nchw(const float* x, int BC, int Hin, int Win, float* y
 }
 
 // NCHW <-> channels-last window, 32x32 tile transpose through LDS (coalesced on both sides)
-__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, int C, int HW, float* __restrict__ y, int ldy, int y_coff) {
+template <class T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, int C, int HW, T* __restrict__ y, int ldy, int y_coff) {
     __shared__ float tile[32][33];
     const int b = blockIdx.z;
     const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -95,23 +117,25 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, int C, int HW, 
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
         const int pq = p0 + i, c = c0 + tx;
-        if (pq < HW && c < C) y[((size_t)b * HW + pq) * ldy + y_coff + c] = tile[tx][i];
+        if (pq < HW && c < C) y[((size_t)b * HW + pq) * ldy + y_coff + c] = (T)tile[tx][i];
     }
 }
-hipError_t launch_nchw_to_nhwc(const float* x, int B, int C, int H, int W, float* y, int ldy, int y_coff, hipStream_t s) {
+hipError_t launch_nchw_to_nhwc(const float* x, int B, int C, int H, int W, float* y, int ldy, int y_coff, hipStream_t s, int bf16) {
     const int HW = H * W;
     dim3 grid((HW + 31) / 32, (C + 31) / 32, B);
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, s, x, C, HW, y, ldy, y_coff);
+    if (bf16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<__bf16>, grid, dim3(256), 0, s, x, C, HW, reinterpret_cast<__bf16*>(y), ldy, y_coff);
+    else hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, s, x, C, HW, y, ldy, y_coff);
     return hipGetLastError();
 }
-__global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, int C, int HW, int ldx, int x_coff, float* __restrict__ y) {
+template <class T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, int C, int HW, int ldx, int x_coff, float* __restrict__ y) {
     __shared__ float tile[32][33];
     const int b = blockIdx.z;
     const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int i = ty; i < 32; i += 8) {
         const int pq = p0 + i, c = c0 + tx;
-        tile[i][tx] = (c < C && pq < HW) ? x[((size_t)b * HW + pq) * ldx + x_coff + c] : 0.f;
+        tile[i][tx] = (c < C && pq < HW) ? (float)x[((size_t)b * HW + pq) * ldx + x_coff + c] : 0.f;
     }
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
@@ -119,17 +143,19 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, int C, int HW, 
         if (c < C && pq < HW) y[((size_t)b * C + c) * HW + pq] = tile[tx][i];
     }
 }
-hipError_t launch_nhwc_to_nchw(const float* x, int B, int C, int H, int W, int ldx, int x_coff, float* y, hipStream_t s) {
+hipError_t launch_nhwc_to_nchw(const float* x, int B, int C, int H, int W, int ldx, int x_coff, float* y, hipStream_t s, int bf16) {
     const int HW = H * W;
     dim3 grid((HW + 31) / 32, (C + 31) / 32, B);
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, s, x, C, HW, ldx, x_coff, y);
+    if (bf16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<__bf16>, grid, dim3(256), 0, s, reinterpret_cast<const __bf16*>(x), C, HW, ldx, x_coff, y);
+    else hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, s, x, C, HW, ldx, x_coff, y);
     return hipGetLastError();
 }
 
 // image2patches 'b c (hg h) (wg w) -> b (c hg wg) h w' (birefnet.rs:288-300), written channels-last:
 // y[b][ty][tx][(c*gh + hg)*gw + wg] = x[b][c][hg*th + ty][wg*tw + tx]; channels [Cimg*gh*gw, cpad) are zeroed.
+template <class T>
 __global__ void image2patches_kernel(const float* __restrict__ x, int B, int Cimg, int H, int W, int th, int tw,
-                                     float* __restrict__ y, int ldy, int cpad) {
+                                     T* __restrict__ y, int ldy, int cpad) {
     const int gh = H / th, gw = W / tw;
     const int cout = Cimg * gh * gw;
     const size_t total = (size_t)B * th * tw * cpad;
@@ -145,28 +171,30 @@ __global__ void image2patches_kernel(const float* __restrict__ x, int B, int Cim
             const int hg = t % gh, c = t / gh;
             v = x[(((size_t)b * Cimg + c) * H + hg * th + ty) * W + wg * tw + tx];
         }
-        y[(((size_t)b * th + ty) * tw + tx) * ldy + ch] = v;
+        y[(((size_t)b * th + ty) * tw + tx) * ldy + ch] = (T)v;
     }
 }
 hipError_t launch_image2patches(const float* x, int B, int Cimg, int H, int W, int th, int tw,
-                                float* y, int ldy, int cpad, hipStream_t s) {
+                                float* y, int ldy, int cpad, hipStream_t s, int bf16) {
     if (H % th || W % tw) return hipErrorInvalidValue;
     const size_t total = (size_t)B * th * tw * cpad;
-    hipLaunchKernelGGL(image2patches_kernel, grid1d(total, 256), dim3(256), 0, s, x, B, Cimg, H, W, th, tw, y, ldy, cpad);
+    if (bf16) hipLaunchKernelGGL(image2patches_kernel<__bf16>, grid1d(total, 256), dim3(256), 0, s, x, B, Cimg, H, W, th, tw, reinterpret_cast<__bf16*>(y), ldy, cpad);
+    else hipLaunchKernelGGL(image2patches_kernel<float>, grid1d(total, 256), dim3(256), 0, s, x, B, Cimg, H, W, th, tw, y, ldy, cpad);
     return hipGetLastError();
 }
 
 // x.mean_keepdim(H).mean_keepdim(W) (aspp.rs:314) on a channels-last window.  Two deterministic passes (no float
 // atomics: replicas on different GPUs must agree bit for bit): per-chunk partial sums, then a fixed-order final sum.
 constexpr int GAP_CHUNK = 512;   // pixels per block of pass 1
-__global__ void gap_partial_kernel(const float* __restrict__ x, int HW, int C, int ldx, int x_coff, float* __restrict__ part) {
+template <class T>
+__global__ void gap_partial_kernel(const T* __restrict__ x, int HW, int C, int ldx, int x_coff, float* __restrict__ part) {
     __shared__ float red[4][64];
     const int b = blockIdx.z, chunk = blockIdx.y, nchunks = gridDim.y;
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
     const int p0 = chunk * GAP_CHUNK, p1 = min(HW, p0 + GAP_CHUNK);
     float acc = 0.f;
     if (c < C)
-        for (int pq = p0 + sub; pq < p1; pq += 4) acc += x[((size_t)b * HW + pq) * ldx + x_coff + c];
+        for (int pq = p0 + sub; pq < p1; pq += 4) acc += (float)x[((size_t)b * HW + pq) * ldx + x_coff + c];
     red[sub][threadIdx.x & 63] = acc;
     __syncthreads();
     if (sub == 0 && c < C)
@@ -180,9 +208,10 @@ __global__ void gap_final_kernel(const float* __restrict__ part, int nchunks, in
     out[(size_t)b * C + c] = acc / (float)HW;
 }
 size_t gap_scratch_floats(int B, int HW, int C) { return (size_t)B * ((HW + GAP_CHUNK - 1) / GAP_CHUNK) * C; }
-hipError_t launch_gap_nhwc(const float* x, int B, int HW, int C, int ldx, int x_coff, float* scratch, float* out, hipStream_t s) {
+hipError_t launch_gap_nhwc(const float* x, int B, int HW, int C, int ldx, int x_coff, float* scratch, float* out, hipStream_t s, int bf16) {
     const int nchunks = (HW + GAP_CHUNK - 1) / GAP_CHUNK;
-    hipLaunchKernelGGL(gap_partial_kernel, dim3((C + 63) / 64, nchunks, B), dim3(256), 0, s, x, HW, C, ldx, x_coff, scratch);
+    if (bf16) hipLaunchKernelGGL(gap_partial_kernel<__bf16>, dim3((C + 63) / 64, nchunks, B), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x), HW, C, ldx, x_coff, scratch);
+    else hipLaunchKernelGGL(gap_partial_kernel<float>, dim3((C + 63) / 64, nchunks, B), dim3(256), 0, s, x, HW, C, ldx, x_coff, scratch);
     hipLaunchKernelGGL(gap_final_kernel, dim3((C + 63) / 64, B), dim3(64), 0, s, scratch, nchunks, C, HW, out);
     return hipGetLastError();
 }
@@ -213,43 +242,44 @@ hipError_t launch_small_fc(const float* x, int B, int Cin, const float* w, int l
 
 // GDT gate (birefnet.rs:327-329): attn = sigmoid(conv1x1_16->1(g)); p *= attn (broadcast over channels).
 // One wave per pixel: lanes 0..15 read g, wave-reduce, then the whole wave scales the C channels.
-__global__ void gdt_gate_kernel(float* __restrict__ p, size_t npix, int C4, int ldp, int p_coff, const float* __restrict__ g,
+template <class T>
+__global__ void gdt_gate_kernel(T* __restrict__ p, size_t npix, int C4, int ldp, int p_coff, const T* __restrict__ g,
                                 int ldg, const float* __restrict__ w, float bias) {
     const int lane = threadIdx.x & 63;
     const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const size_t nwaves = (size_t)gridDim.x * (blockDim.x >> 6);
     for (size_t pix = wave; pix < npix; pix += nwaves) {
-        float d = lane < 16 ? g[pix * ldg + lane] * w[lane] : 0.f;
+        float d = lane < 16 ? (float)g[pix * ldg + lane] * w[lane] : 0.f;
         d += __shfl_xor(d, 8); d += __shfl_xor(d, 4); d += __shfl_xor(d, 2); d += __shfl_xor(d, 1);
         d = __shfl(d, 0);
         const float a = 1.0f / (1.0f + expf(-(d + bias)));
-        float* row = p + pix * ldp + p_coff;
-        for (int c4 = lane; c4 < C4; c4 += 64) {
-            f32x4 v = *reinterpret_cast<f32x4*>(row + c4 * 4);
-            *reinterpret_cast<f32x4*>(row + c4 * 4) = v * a;
-        }
+        T* row = p + pix * ldp + p_coff;
+        for (int c4 = lane; c4 < C4; c4 += 64) st4<T>(row + c4 * 4, ld4<T>(row + c4 * 4) * a);
     }
 }
 hipError_t launch_gdt_gate(float* p, int npix, int C, int ldp, int p_coff, const float* g, int ldg,
-                           const float* w, float bias, hipStream_t s) {
+                           const float* w, float bias, hipStream_t s, int bf16) {
     if (C % 4) return hipErrorInvalidValue;
     size_t blocks = ((size_t)npix + 3) / 4;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(gdt_gate_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, (size_t)npix, C / 4, ldp, p_coff, g, ldg, w, bias);
+    if (bf16) hipLaunchKernelGGL(gdt_gate_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<__bf16*>(p), (size_t)npix, C / 4, ldp, p_coff,
+                                 reinterpret_cast<const __bf16*>(g), ldg, w, bias);
+    else hipLaunchKernelGGL(gdt_gate_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, p, (size_t)npix, C / 4, ldp, p_coff, g, ldg, w, bias);
     return hipGetLastError();
 }
 
 // per-pixel dot product over channels: y[pix] = <x[pix][0:C], w> + bias.  16 lanes per pixel.
-__global__ void pixel_dot_kernel(const float* __restrict__ x, size_t npix, int C4, int ldx, int x_coff,
+template <class T>
+__global__ void pixel_dot_kernel(const T* __restrict__ x, size_t npix, int C4, int ldx, int x_coff,
                                  const float* __restrict__ w, float bias, float* __restrict__ y) {
     const int sub = threadIdx.x & 15;
     const size_t grp = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const size_t ngrp = ((size_t)gridDim.x * blockDim.x) >> 4;
     for (size_t pix = grp; pix < npix; pix += ngrp) {
-        const float* row = x + pix * ldx + x_coff;
+        const T* row = x + pix * ldx + x_coff;
         float acc = 0.f;
         for (int c4 = sub; c4 < C4; c4 += 16) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(row + c4 * 4);
+            const f32x4 v = ld4<T>(row + c4 * 4);
             const f32x4 ww = *reinterpret_cast<const f32x4*>(w + c4 * 4);
             acc += (v[0] * ww[0] + v[1] * ww[1]) + (v[2] * ww[2] + v[3] * ww[3]);
         }
@@ -258,11 +288,12 @@ __global__ void pixel_dot_kernel(const float* __restrict__ x, size_t npix, int C
     }
 }
 hipError_t launch_pixel_dot(const float* x, int npix, int C, int ldx, int x_coff, const float* w, float bias,
-                            float* y, hipStream_t s) {
+                            float* y, hipStream_t s, int bf16) {
     if (C % 4) return hipErrorInvalidValue;
     size_t blocks = ((size_t)npix * 16 + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(pixel_dot_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, (size_t)npix, C / 4, ldx, x_coff, w, bias, y);
+    if (bf16) hipLaunchKernelGGL(pixel_dot_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x), (size_t)npix, C / 4, ldx, x_coff, w, bias, y);
+    else hipLaunchKernelGGL(pixel_dot_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, x, (size_t)npix, C / 4, ldx, x_coff, w, bias, y);
     return hipGetLastError();
 }
 
@@ -293,6 +324,15 @@ hipError_t launch_final_head(const float* q, int B, int h, int w, const float* t
                              int apply_sigmoid, float* out, hipStream_t s) {
     const size_t total = (size_t)B * H * W;
     hipLaunchKernelGGL(final_head_kernel, grid1d(total, 256), dim3(256), 0, s, q, B, h, w, t, bias, H, W, apply_sigmoid, out);
+    return hipGetLastError();
+}
+
+// fp32 -> bf16 (RNE) of a contiguous buffer: the op-level entry points in compute mode BRN_BF16 convert their operands at the edge
+__global__ void f32_to_bf16_kernel(const float* __restrict__ x, size_t n, __bf16* __restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = (__bf16)x[i];
+}
+hipError_t launch_f32_to_bf16(const float* x, size_t n, float* y_bf16, hipStream_t s) {
+    hipLaunchKernelGGL(f32_to_bf16_kernel, grid1d(n, 256), dim3(256), 0, s, x, n, reinterpret_cast<__bf16*>(y_bf16));
     return hipGetLastError();
 }
 

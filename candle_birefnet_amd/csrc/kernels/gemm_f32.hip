@@ -26,12 +26,17 @@ __device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; retur
 // a load the optimiser may not sink under the predicate that later selects its value: hipcc turns `ok ? *p : 0` (and
 // `t = *p; ok ? t : 0`) into an exec-branch around the load, and then waits vmcnt(0) before the first use of ANY staged
 // register in the loop, draining the prefetched K tiles every iteration.
-// So: load from a clamped (always valid) address, remember a 1.0 / 0.0 mask, and zero the value arithmetically when the
-// staged registers are consumed (x * mask at the LDS store) — never a select at the load, never arithmetic at the load
-// (that would wait for the data right there).
-__device__ __forceinline__ f32x4 load4_masked(const float* ptr, bool ok, float& mask) {
-    mask = ok ? 1.0f : 0.0f;
+// So: load from a clamped (always valid) address, remember a ~0 / 0 bit mask, and AND the value with it when the staged
+// registers are consumed (at the LDS store) — never a select at the load, never an operation on the data at the load (that
+// would wait for it right there).  An integer AND, not a multiply by 0/1: the clamped address holds real data (pixel (0,0) of
+// the window, row 0), and Inf * 0 = NaN would leak a non-finite input into every zero-padded border output.
+__device__ __forceinline__ f32x4 load4_masked(const float* ptr, bool ok, unsigned& keep) {
+    keep = ok ? 0xffffffffu : 0u;
     return *reinterpret_cast<const f32x4*>(ptr);
+}
+__device__ __forceinline__ f32x4 and4(const f32x4 v, const unsigned keep) {
+    typedef unsigned u32x4_m __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4_m, v) & keep);
 }
 
 constexpr int BK = 32;
@@ -141,7 +146,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                 if (p.scale) v = v * sc + sh;
                 v = act4(v, p.act);
                 float* dst = p.C + (long)m * p.ldc + p.c_coff + n;
-                if (vec) {
+                if (p.c_bf16) {                 // compute mode BRN_BF16 (deformable gather convs): bf16 map out, no residual on this path
+                    __bf16* db = reinterpret_cast<__bf16*>(p.C) + (long)m * p.ldc + p.c_coff + n;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (n + e < p.N) db[e] = (__bf16)v[e];
+                } else if (vec) {
                     if (p.R) v = v + *reinterpret_cast<const f32x4*>(p.R + (long)m * p.ldr + p.r_coff + n);
                     *reinterpret_cast<f32x4*>(dst) = v;
                 } else {
@@ -220,9 +229,9 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_f32_kernel(const GemmParams 
     const float* wrow = p.W + (long)(n0 + lrow) * p.K + kq * 4;
 
     f32x4 ra[PA], rb[PB];
-    float am[PA];
+    unsigned am[PA];
 #pragma unroll
-    for (int i = 0; i < PA; ++i) am[i] = 1.0f;
+    for (int i = 0; i < PA; ++i) am[i] = 0xffffffffu;
 
     auto gload = [&](int kt) {
         const int k0 = kt * BK;
@@ -279,12 +288,22 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_f32_kernel(const GemmParams 
                         const int yh = yl + 1, xh = xl + 1;
                         const float ly = y - (float)yl, lx = x - (float)xl;
                         const float hy = 1.f - ly, hx = 1.f - lx;
-                        const float* base = p.A + a_base[i] + ci0 + kq * 4;
+                        const long boff = a_base[i] + ci0 + kq * 4;
+                        // compute mode BRN_BF16: the sampled map is bf16 (lda / a_coff in elements either way)
+                        auto tap4 = [&](int yy, int xx) -> f32x4 {
+                            const long o = boff + ((long)yy * p.Win + xx) * p.lda;
+                            if (p.a_bf16) {
+                                const bf16x4 h = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(p.A) + o);
+                                f32x4 r4 = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+                                return r4;
+                            }
+                            return *reinterpret_cast<const f32x4*>(p.A + o);
+                        };
                         f32x4 v1 = zero4(), v2 = v1, v3 = v1, v4 = v1;
-                        if (yl >= 0 && xl >= 0) v1 = *reinterpret_cast<const f32x4*>(base + ((long)yl * p.Win + xl) * p.lda);
-                        if (yl >= 0 && xh <= p.Win - 1) v2 = *reinterpret_cast<const f32x4*>(base + ((long)yl * p.Win + xh) * p.lda);
-                        if (yh <= p.Hin - 1 && xl >= 0) v3 = *reinterpret_cast<const f32x4*>(base + ((long)yh * p.Win + xl) * p.lda);
-                        if (yh <= p.Hin - 1 && xh <= p.Win - 1) v4 = *reinterpret_cast<const f32x4*>(base + ((long)yh * p.Win + xh) * p.lda);
+                        if (yl >= 0 && xl >= 0) v1 = tap4(yl, xl);
+                        if (yl >= 0 && xh <= p.Win - 1) v2 = tap4(yl, xh);
+                        if (yh <= p.Hin - 1 && xl >= 0) v3 = tap4(yh, xl);
+                        if (yh <= p.Hin - 1 && xh <= p.Win - 1) v4 = tap4(yh, xh);
                         const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
                         r = mk * (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4);
                     }
@@ -296,7 +315,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_f32_kernel(const GemmParams 
     auto lds_store = [&]() {
 #pragma unroll
         for (int i = 0; i < PA; ++i)
-            *reinterpret_cast<f32x4*>(As + (lrow + i * RPP) * LDS_LD + kq * 4) = ra[i] * am[i];
+            *reinterpret_cast<f32x4*>(As + (lrow + i * RPP) * LDS_LD + kq * 4) = and4(ra[i], am[i]);
 #pragma unroll
         for (int i = 0; i < PB; ++i)
             *reinterpret_cast<f32x4*>(Bs + (lrow + i * RPP) * LDS_LD + kq * 4) = rb[i];
@@ -431,9 +450,9 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_split_kernel(const GemmParam
     // bandwidth, bound this kernel: a bf16-rate K tile lasts a few hundred cycles, an L2/HBM round trip ~1-2 thousand)
     f32x4 ra[2][PA];
     bf16x8 rb[2][NP][PB];
-    float am[2][PA];
+    unsigned am[2][PA];
 
-    auto gload = [&](int kt, f32x4 (&qa)[PA], bf16x8 (&qb)[NP][PB], float (&qm)[PA]) {
+    auto gload = [&](int kt, f32x4 (&qa)[PA], bf16x8 (&qb)[NP][PB], unsigned (&qm)[PA]) {
         const int k0 = kt * BK;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
@@ -459,7 +478,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_split_kernel(const GemmParam
             }
         }
     };
-    auto lds_store = [&](const f32x4 (&qa)[PA], const bf16x8 (&qb)[NP][PB], const float (&qm)[PA]) {
+    auto lds_store = [&](const f32x4 (&qa)[PA], const bf16x8 (&qb)[NP][PB], const unsigned (&qm)[PA]) {
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             bf16x4 sp[NP];
@@ -706,8 +725,8 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
         const __bf16* wsrc = reinterpret_cast<const __bf16*>(p.Wp) + (long)(n0 + wrow) * wrow_stride + wc * 8;
         f32x4 ra[2][PA];
         bf16x8 rb[2][NP][PB];
-        float am[2][PA];
-        auto gload = [&](int t, f32x4 (&qa)[PA], bf16x8 (&qb)[NP][PB], float (&qm)[PA]) {
+        unsigned am[2][PA];
+        auto gload = [&](int t, f32x4 (&qa)[PA], bf16x8 (&qb)[NP][PB], unsigned (&qm)[PA]) {
             const int k0 = (kt0 + t) * KS;
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
@@ -740,7 +759,7 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
                 }
             }
         };
-        auto lds_store = [&](int t, const f32x4 (&qa)[PA], const bf16x8 (&qb)[NP][PB], const float (&qm)[PA]) {
+        auto lds_store = [&](int t, const f32x4 (&qa)[PA], const bf16x8 (&qb)[NP][PB], const unsigned (&qm)[PA]) {
             __bf16* As = smem + (t % NBUF) * BUF;
             __bf16* Bs = As + NP * BM * SLD;
             if (APL) {
@@ -749,8 +768,7 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
 #pragma unroll
                 for (int i = 0; i < PA; ++i) {
                     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                    const unsigned keep = qm[i] != 0.f ? 0xffffffffu : 0u;
-                    const u32x4 bits = __builtin_bit_cast(u32x4, qa[i]) & keep;
+                    const u32x4 bits = __builtin_bit_cast(u32x4, qa[i]) & qm[i];
                     *reinterpret_cast<u32x4*>(As + p_lds[i]) = bits;
                 }
             } else {
@@ -885,14 +903,18 @@ static hipError_t launch_split_ws_ks(const GemmParams& p, dim3 grid, hipStream_t
     if (p.a_planes) {
         if constexpr (NP == 2 && KS == 32) {   // (the 3-plane form works too, but was 2 % slower per forward: rows 1.5x as long)
             if (p.mode != GEMM_DENSE || p.a_planes != NP) return hipErrorInvalidValue;
-            if (p.abl || p.trace) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, 2, 32, true, true>), grid, block, 0, s, p);
-            else hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, 2, 32, false, true>), grid, block, 0, s, p);
+#ifdef BRN_DIAG_BUILD
+            if (p.abl || p.trace) { hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, 2, 32, true, true>), grid, block, 0, s, p); return hipGetLastError(); }
+#endif
+            hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, 2, 32, false, true>), grid, block, 0, s, p);
             return hipGetLastError();
         }
         return hipErrorInvalidValue;
     }
-    if (p.mode == GEMM_DENSE && KS == 32 && (p.abl || p.trace)) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, NP, 32, true, false>), grid, block, 0, s, p);
-    else if (p.mode == GEMM_DENSE) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, NP, KS, false, false>), grid, block, 0, s, p);
+#ifdef BRN_DIAG_BUILD
+    if (p.mode == GEMM_DENSE && KS == 32 && (p.abl || p.trace)) { hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, NP, 32, true, false>), grid, block, 0, s, p); return hipGetLastError(); }
+#endif
+    if (p.mode == GEMM_DENSE) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, NP, KS, false, false>), grid, block, 0, s, p);
     else if (p.mode == GEMM_CONV_NHWC) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_CONV_NHWC, NP, KS, false, false>), grid, block, 0, s, p);
     else return hipErrorInvalidValue;
     return hipGetLastError();
@@ -917,6 +939,7 @@ static hipError_t launch_split_cfg(const GemmParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
+#ifdef BRN_DIAG_BUILD   // probe kernels: only in libbirefnet_hip_diag.so (include/birefnet_hip_diag.h)
 // diagnostic: the consumer inner loop of the split kernels in isolation — fragments from LDS (ds_read_b128, conflict-free
 // layout of the real kernel), NPAIR MFMAs per (i,j) sub-tile, no global memory, no barriers.  variant 0: reads of a k-step
 // issued right before its MFMAs; variant 1: next k-step's fragments prefetched into a second register set.
@@ -1145,6 +1168,8 @@ hipError_t launch_mfma_peak(int blocks, int iters, float* sink, unsigned long lo
     return hipGetLastError();
 }
 
+#endif  // BRN_DIAG_BUILD
+
 // split-K second pass: fixed-order sum of the slices (deterministic) + the epilogue of gemm_f32_kernel
 __global__ void splitk_reduce_kernel(const GemmParams p) {
     const long total = (long)p.M * p.N;
@@ -1227,6 +1252,8 @@ hipError_t launch_gemm(const GemmParams& p_in, const GemmPlan& pl, float* ws, hi
     p.splitk = pl.splitk < 1 ? 1 : pl.splitk;
     p.part = ws;
     if (p.splitk > 1 && !ws) return hipErrorInvalidValue;
+    if (p.a_bf16 && p.mode != GEMM_DEFORM_NHWC) return hipErrorInvalidValue;       // only the deformable loader reads bf16 maps here
+    if (p.c_bf16 && (p.splitk > 1 || p.R || (p.planes > 0 && p.Wp && p.mode != GEMM_DEFORM_NHWC && p.mode != GEMM_GATHER_NCHW))) return hipErrorInvalidValue;
     if (p.a_planes || p.c_planes) {         // P2 layouts: 2-plane split mode, dense, on the warp-specialised kernel only
         const bool ws_cfg = pl.cfg == 6 || pl.cfg == 0 || pl.cfg == 3 || pl.cfg == 4 || pl.cfg == 5;
         if (!(p.planes == 2 || p.planes == 3) || !p.Wp || p.mode != GEMM_DENSE || !ws_cfg) return hipErrorInvalidValue;

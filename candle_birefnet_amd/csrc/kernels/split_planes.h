@@ -8,20 +8,21 @@ typedef float f32x4_sp __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-// Error-free split of four fp32 values (times a 0/1 row mask) into NP bf16 planes: plane 0 = RNE bf16(x), plane p+1 = RNE
+// Error-free split of four fp32 values (AND-ed with a 0 / ~0 row mask: a masked element is +0 whatever was loaded from the clamped
+// address, NaN and Inf included — candle's conv zero-pads) into NP bf16 planes: plane 0 = RNE bf16(x), plane p+1 = RNE
 // bf16 of what is left.  Written with one-instruction asm pieces on purpose: left to the compiler, the multiplies and
 // subtractions become packed-fp32 instructions (v_pk_mul_f32 / v_pk_fma_f32 with op_sel), and with those this kernel's
 // producer waves stored wrong A rows a few times per 10^5 K tiles while MFMA waves shared their SIMD (always the last 16
 // lanes, always the op_sel'd operand; tools/race_ints.py is the reproducer).  Plain VALU forms are also cheaper beside MFMAs.
-__device__ __forceinline__ float valu_mul(float a, float b) { float r; asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float valu_and(float a, unsigned keep) { float r; asm("v_and_b32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(keep)); return r; }
 __device__ __forceinline__ float valu_sub(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ unsigned valu_cvt_pk_bf16(float a, float b) { unsigned r; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 template <int NP>
-__device__ __forceinline__ void split4(const f32x4_sp v, const float mask, bf16x4 (&out)[NP]) {
+__device__ __forceinline__ void split4(const f32x4_sp v, const unsigned keep, bf16x4 (&out)[NP]) {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     float r[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) r[e] = valu_mul(v[e], mask);
+    for (int e = 0; e < 4; ++e) r[e] = valu_and(v[e], keep);
 #pragma unroll
     for (int pl = 0; pl < NP; ++pl) {
         u32x2 h;
@@ -46,7 +47,7 @@ __device__ __forceinline__ void split4(const f32x4_sp v, const float mask, bf16x
 template <int NP>
 __device__ __forceinline__ void store_planes(float* row, int col, const f32x4_sp v) {
     bf16x4 sp[NP];
-    split4<NP>(v, 1.0f, sp);
+    split4<NP>(v, 0xffffffffu, sp);
     char* base = reinterpret_cast<char*>(row) + (col >> 5) * (64 * NP) + (col & 31) * 2;
 #pragma unroll
     for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<bf16x4*>(base + 64 * pl) = sp[pl];

@@ -383,6 +383,160 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_split_kernel(con
     }
 }
 
+// =====================================================================================================================
+// window_attention_bf16_kernel — compute mode BRN_BF16: qkv arrives as bf16 (the qkv GEMM's output), `out` leaves as bf16
+// (the proj GEMM's input).  Same structure and LDS images as window_attention_split_kernel<1>; what changes is the staging
+// (16-byte loads of 8 bf16, no split) and that q's scale is applied to the fp32 scores instead of to q (q is already
+// rounded to bf16: scaling the accumulator avoids a second rounding; identical in real arithmetic, swin.rs:278).
+// =====================================================================================================================
+__device__ __forceinline__ bf16x8 bias8_bf16(const float* bp) {
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (__bf16)bp[e];
+    return r;
+}
+
+__global__ void __launch_bounds__(ATT_THREADS) window_attention_bf16_kernel(const WindowAttnParams pa, const WindowAttnParams pb, const int nblk0) {
+    const bool second = (int)blockIdx.x >= nblk0;
+    const WindowAttnParams& p = second ? pb : pa;
+    __shared__ __attribute__((aligned(16))) __bf16 Kp[NTOK * HD];
+    __shared__ __attribute__((aligned(16))) __bf16 Vt[HD * VT_LD];
+    __shared__ float tab_s[(2 * WS - 1) * (2 * WS - 1)];
+    __shared__ int src_s[NTOK];
+    __shared__ unsigned char rid_s[NTOK];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int head = blockIdx.y;
+    const int nWw = p.Wp / WS, nW = (p.Hp / WS) * nWw;
+    const int bw = second ? (int)blockIdx.x - nblk0 : (int)blockIdx.x;
+    const int b = bw / nW, w = bw - b * nW;
+    const int wr = w / nWw, wc = w - wr * nWw;
+    const int C = p.C, C3 = 3 * C;
+    const __bf16* qkv = reinterpret_cast<const __bf16*>(p.qkv);
+
+    if (tid < NTOK) {
+        const int ti = tid / WS, tj = tid - ti * WS;
+        const int ph = wr * WS + ti, pw = wc * WS + tj;
+        int sh = ph + p.shift, sw = pw + p.shift;
+        if (sh >= p.Hp) sh -= p.Hp;
+        if (sw >= p.Wp) sw -= p.Wp;
+        src_s[tid] = (sh < p.H && sw < p.W) ? (b * p.H + sh) * p.W + sw : -1;
+        const int fh = ph < p.Hp - WS ? 0 : (ph < p.Hp - p.shift ? 1 : 2);
+        const int fw = pw < p.Wp - WS ? 0 : (pw < p.Wp - p.shift ? 1 : 2);
+        rid_s[tid] = (unsigned char)(fh * 3 + fw);
+    }
+    for (int i = tid; i < (2 * WS - 1) * (2 * WS - 1); i += ATT_THREADS) tab_s[i] = p.rel_table[head * ((2 * WS - 1) * (2 * WS - 1)) + i];
+    __syncthreads();
+
+    // ---- stage K (row-major, chunk-swizzled) and V (transposed): items = (token pair, 8-wide d chunk) ----
+    for (int idx = tid; idx < (NTOK / 2) * 4; idx += ATT_THREADS) {
+        const int tp = idx >> 2, c8 = (idx & 3) * 8;
+        bf16x8 kv[2], vv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = tp * 2 + u, src = src_s[t];
+            if (src >= 0) {
+                const __bf16* kp = qkv + (long)src * C3 + C + head * HD + c8;
+                kv[u] = *reinterpret_cast<const bf16x8*>(kp);
+                vv[u] = *reinterpret_cast<const bf16x8*>(kp + C);
+            } else {          // pad token: LayerNorm output row is zero, so q / k / v = the qkv bias (swin.rs:359-366)
+                kv[u] = bias8_bf16(p.qkv_bias + C + head * HD + c8);
+                vv[u] = bias8_bf16(p.qkv_bias + 2 * C + head * HD + c8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = tp * 2 + u;
+            *reinterpret_cast<bf16x8*>(Kp + t * HD + (((c8 >> 3) ^ kswz(t)) << 3)) = kv[u];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            bf16x2 h;
+            h[0] = vv[0][e]; h[1] = vv[1][e];
+            *reinterpret_cast<bf16x2*>(Vt + (c8 + e) * VT_LD + tp * 2) = h;
+        }
+    }
+    __syncthreads();
+
+    const int li = lane & 15, g = lane >> 4;
+    for (int qt = wave; qt < 9; qt += 3) {
+        const int qtok = qt * 16 + li;
+        const int qsrc = src_s[qtok];
+        const int qrid = rid_s[qtok];
+        const int qbase = (qtok / WS + WS - 1) * (2 * WS - 1) + (qtok % WS) + WS - 1;
+        bf16x8 qf;
+        if (qsrc >= 0) qf = *reinterpret_cast<const bf16x8*>(qkv + (long)qsrc * C3 + head * HD + g * 8);
+        else qf = bias8_bf16(p.qkv_bias + head * HD + g * 8);
+        f32x4 st[9];
+#pragma unroll
+        for (int kt = 0; kt < 9; ++kt) {
+            const int key = kt * 16 + li;
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kp + key * HD + ((g ^ kswz(key)) << 3));
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, acc, 0, 0, 0);
+            if (kt % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+        }
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kt = 0; kt < 9; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + g * 4 + r;
+                float sv = st[kt][r] * p.scale + tab_s[qbase - key - 11 * (key / WS)];
+                if (p.shift > 0) sv += ((int)rid_s[key] != qrid) ? -100.0f : 0.0f;
+                st[kt][r] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 9; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(st[kt][r] - mx);
+                st[kt][r] = e;
+                sum += e;
+            }
+        }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            bf16x8 pf;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                pf[e] = (__bf16)st[2 * t][e];
+                pf[4 + e] = (2 * t + 1 < 9) ? (__bf16)st[(2 * t + 1 < 9) ? 2 * t + 1 : 0][e] : (__bf16)0.f;
+            }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const __bf16* vrow = Vt + (dt * 16 + li) * VT_LD + g * 4;
+                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow + (2 * t) * 16);
+                bf16x4 hi = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+                if (2 * t + 1 < 9) hi = *reinterpret_cast<const bf16x4*>(vrow + (2 * t + 1) * 16);
+                bf16x8 vf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
+                if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o0, 0, 0, 0);
+                else o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o1, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (qsrc >= 0) {
+            const float inv = 1.0f / sum;
+            __bf16* op = reinterpret_cast<__bf16*>(p.out) + (long)qsrc * C + head * HD + g * 4;
+            bf16x4 h0, h1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { h0[e] = (__bf16)(o0[e] * inv); h1[e] = (__bf16)(o1[e] * inv); }
+            *reinterpret_cast<bf16x4*>(op) = h0;
+            *reinterpret_cast<bf16x4*>(op + 16) = h1;
+        }
+    }
+}
+
 static hipError_t check_attention(const WindowAttnParams& p) {
     if (p.C != p.heads * HD || p.Hp % WS || p.Wp % WS || p.Hp < p.H || p.Wp < p.W) return hipErrorInvalidValue;
     if (!(p.shift == 0 || p.shift == WS / 2)) return hipErrorInvalidValue;
@@ -393,13 +547,16 @@ hipError_t launch_window_attention2(const WindowAttnParams& p, const WindowAttnP
     const int n0 = p.B * (p.Hp / WS) * (p.Wp / WS);
     int n1 = 0;
     if (p2) {
-        if (check_attention(*p2) != hipSuccess || p2->C != p.C || p2->heads != p.heads || p2->planes != p.planes || p2->out_planes != p.out_planes) return hipErrorInvalidValue;
+        if (check_attention(*p2) != hipSuccess || p2->C != p.C || p2->heads != p.heads || p2->planes != p.planes || p2->out_planes != p.out_planes || p2->io_bf16 != p.io_bf16) return hipErrorInvalidValue;
         n1 = p2->B * (p2->Hp / WS) * (p2->Wp / WS);
     }
     if (p.out_planes && !((p.out_planes == 2 && p.planes == 2) || (p.out_planes == 3 && p.planes == 0))) return hipErrorInvalidValue;
     const WindowAttnParams& q = p2 ? *p2 : p;
     dim3 grid(n0 + n1, p.heads), block(ATT_THREADS);
-    if (p.planes == 2) hipLaunchKernelGGL(window_attention_split_kernel<2>, grid, block, 0, s, p, q, n0);
+    if (p.io_bf16) {
+        if (p.out_planes || (p.C & 7)) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(window_attention_bf16_kernel, grid, block, 0, s, p, q, n0);
+    } else if (p.planes == 2) hipLaunchKernelGGL(window_attention_split_kernel<2>, grid, block, 0, s, p, q, n0);
     else if (p.planes == 1) hipLaunchKernelGGL(window_attention_split_kernel<1>, grid, block, 0, s, p, q, n0);
     else hipLaunchKernelGGL(window_attention_f32_kernel, grid, block, 0, s, p, q, n0);
     return hipGetLastError();

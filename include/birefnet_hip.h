@@ -12,6 +12,9 @@
  *     model's device; BRN_MEM_HOST buffers are staged through HBM by the library (H2D/D2H on `stream`).
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are asynchronous for
  *     BRN_MEM_DEVICE buffers and synchronous (stream-synchronised before return) for BRN_MEM_HOST output.
+ *     A model handle owns ONE workspace: forwards on it are serialised on the host by a mutex and, when consecutive calls
+ *     use different streams, on the GPU by an event (the later call's stream waits for the earlier forward's last kernel),
+ *     so a handle may be driven from several threads / streams; for concurrent forwards use one handle per stream.
  *   - image tensors at this boundary are NCHW like candle's (infer_image.rs:67); the library's internal
  *     layout (NHWC) is not visible.
  *   - there is NO CPU fallback: every call needs a HIP device and fails with BRN_ERR_NO_DEVICE without one.
@@ -40,14 +43,17 @@ enum {
 };
 
 typedef enum { BRN_MEM_HOST = 0, BRN_MEM_DEVICE = 1 } brn_mem;
-/* Arithmetic of the contraction kernels (everything else — LayerNorm, softmax, epilogues, storage — is fp32; the
- * reference runs DType::F32, infer_image.rs:26):
+/* Arithmetic of the contraction kernels.  In the first four modes everything else — LayerNorm, softmax, epilogues,
+ * storage — is fp32 (the reference runs DType::F32, infer_image.rs:26):
  *   BRN_F32            fp32 operands on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32), exact fmaf chain
  *   BRN_F32_SPLIT3     fp32 operands split error-free into 3 bf16 planes, 6 bf16 MFMAs per product, fp32 accumulate:
  *                      fp32-class accuracy (dropped terms < 2^-24 of a product) at 2.67x the fp32-MFMA rate
  *   BRN_F32_SPLIT2     2 planes, 3 MFMAs: ~2^-16 relative per product
- *   BRN_BF16_OPERANDS  operands rounded to bf16, fp32 accumulate (the bf16 throughput mode; parity is informational) */
-typedef enum { BRN_F32 = 0, BRN_F32_SPLIT3 = 1, BRN_F32_SPLIT2 = 2, BRN_BF16_OPERANDS = 3 } brn_dtype;
+ *   BRN_BF16_OPERANDS  operands rounded to bf16, fp32 accumulate, fp32 storage (parity is informational)
+ *   BRN_BF16           the bf16 throughput mode of BASELINE configs[2..4]: activations AND weights live in HBM as bf16,
+ *                      bf16 MFMA with fp32 accumulation, fp32 statistics inside LayerNorm / softmax / GAP; x and the logits
+ *                      stay fp32 at this boundary.  Parity is informational (error vs the fp32 oracle is reported). */
+typedef enum { BRN_F32 = 0, BRN_F32_SPLIT3 = 1, BRN_F32_SPLIT2 = 2, BRN_BF16_OPERANDS = 3, BRN_BF16 = 4 } brn_dtype;
 
 /* D1 of SURVEY.md §8: what DeformConvASPP::forward computes.
  * REFERENCE_CPU = aspp.rs:183-185 (offset/modulator discarded, regular_conv(x)) — the graded parity target.
@@ -221,13 +227,6 @@ brn_status brn_preprocess_image(const unsigned char* pixels, int h, int w, int c
  * [out_h][out_w] u8 on the host. */
 brn_status brn_postprocess_mask(const float* logits, int S, brn_mem in_loc, int apply_sigmoid, int out_h, int out_w,
                                 unsigned char* mask_out, int device_ordinal, void* stream);
-
-/* ---- diagnostics ---------------------------------------------------------------------------------------- */
-/* Times `iters` launches of the dense gemm_f32 kernel on random device data (M x K times N x K^T).  tile_cfg: -1 = the
- * library's own plan, 0 = 128x128, 1 = 128x64, 2 = 64x64 block tile; splitk only with tile_cfg >= 0; add 1000*planes
- * (planes 1..3) for the split-bf16 kernel (1999/2999/3999 = library plan with 1/2/3 planes).  Tuning aid. */
-brn_status brn_gemm_microbench(int M, int N, int K, int tile_cfg, int splitk, int iters, int device_ordinal,
-                               float* ms_per_launch);
 
 #ifdef __cplusplus
 }

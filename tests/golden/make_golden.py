@@ -6,7 +6,8 @@ oracle and the HIP path to an independent restatement of the same Rust sources, 
 Weights and inputs are never stored: both sides regenerate them from seeds (candle_birefnet_amd.weights, numpy Philox);
 `weights_checksum` guards against PRNG drift.
 
-  python tests/golden/make_golden.py [--full1024]        (the 1024x1024 fp64 run takes several minutes and ~20 GB)
+  python tests/golden/make_golden.py [--full1024 | --full2048]   (the 1024x1024 fp64 run takes several minutes and ~20 GB;
+                                                                  --full2048 runs the restatement in fp32)
 """
 import argparse
 import os
@@ -102,6 +103,21 @@ def full1024():
     return out
 
 
+def full2048():
+    """BASELINE configs[4] geometry (2048x2048, B=1) through the torch restatement in fp32 (fp64 does not fit this container's
+    62 GiB): every 32nd pixel + global statistics.  fp32-vs-fp32: the GPU test's tolerance is the north-star gate."""
+    cfg = BiRefNetConfig()
+    w = synth_weights(birefnet_weight_spec(cfg), seed=42)
+    x = synth_input(1, 2048, 2048)
+    t = time.time()
+    with torch.no_grad():
+        y = R.forward_logits(x, w, cfg, torch.float32)
+    print("2048 fp32 restatement", f"{time.time() - t:.1f}s", flush=True)
+    yn = y.numpy().astype(np.float64)
+    return {"m2048_full_ref_s32": yn[:, :, ::32, ::32].astype(np.float32),
+            "m2048_full_ref_stats": np.array([yn.sum(), np.abs(yn).sum(), yn.min(), yn.max()], np.float64)}
+
+
 def weights_checksum():
     names = [("bb.layers.0.blocks.0.attn.qkv.weight", (576, 192), "lin_w"), ("decoder.conv_out1.0.weight", (1, 240, 1, 1), "conv_w"),
              ("bb.layers.3.blocks.1.attn.relative_position_bias_table", (529, 48), "rel_bias"),
@@ -113,9 +129,12 @@ def weights_checksum():
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full1024", action="store_true")
+    ap.add_argument("--full2048", action="store_true")
     a = ap.parse_args()
     torch.set_num_threads(os.cpu_count() or 1)
-    if a.full1024:
+    if a.full2048:
+        np.savez_compressed(os.path.join(HERE, "model_2048.npz"), **full2048())
+    elif a.full1024:
         np.savez_compressed(os.path.join(HERE, "model_1024.npz"), **full1024())
     else:
         np.savez_compressed(os.path.join(HERE, "kats.npz"), **kats())

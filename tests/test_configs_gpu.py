@@ -1,0 +1,105 @@
+"""BASELINE.json configs[2..4] under -m gpu: B=8 1024^2 in the bf16 modes, 2048^2 against a committed golden
+(fp32 torch restatement, tests/golden/make_golden.py --full2048) and through the batch-independence property, and the N>1
+product path (two processes, two handles, one device) against one process."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import golden_cases as G
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(HERE, "golden")
+# bf16 modes are throughput modes: the fp32 gate (1e-3 abs | 1e-2 rel) does not apply; their error against the fp64 / fp32
+# restatement is REPORTED and bounded here.  |logit| max of the 1024^2 synthetic run is ~2.2.
+BF16_ABS_BOUND = {"bf16_operands": 2e-2, "bf16": 3e-2}   # measured on MI355X: 4.3e-3 / 6.2e-3 (1024^2), 4.4e-3 / 7.2e-3 (2048^2)
+
+
+def _full_model(mode, max_batch=0, size=0):
+    import candle_birefnet_amd as cb
+    cfg = cb.BiRefNetConfig()
+    w = cb.synth_weights(cb.birefnet_weight_spec(cfg), seed=42)
+    return cb, cb.BiRefNet.new(cfg, cb.VarBuilder.from_tensors(w), compute=mode, max_batch=max_batch, max_size=(size, size))
+
+
+@pytest.mark.parametrize("mode", ["bf16_operands", "bf16"])
+def test_c3_batch8_1024_bf16(gpu, mode):
+    """configs[2] (and one rank of configs[3]): B=8, 1024x1024.  Finite; the same call twice gives the same bits; an image alone
+    equals the same image inside the batch up to the mode's rounding; error vs the strided fp64 golden of image 0 is bounded."""
+    import torch
+    cb, m = _full_model(mode, 8, 1024)
+    x = torch.from_numpy(cb.synth_input(8, 1024, 1024)).cuda()
+    y = m.forward_logits(x)
+    y2 = m.forward_logits(x)
+    assert torch.isfinite(y).all()
+    assert torch.equal(y, y2)                                        # no float atomics anywhere on the path
+    k = np.load(os.path.join(GOLD, "model_1024.npz"))
+    yn = y.cpu().numpy().astype(np.float64)
+    e0 = float(np.abs(yn[0, :, ::16, ::16] - k["m1024_full_ref_s16"][0]).max())
+    alone = [m.forward_logits(x[b:b + 1]).cpu().numpy().astype(np.float64)[0] for b in (0, 5)]
+    d = max(float(np.abs(alone[0] - yn[0]).max()), float(np.abs(alone[1] - yn[5]).max()))
+    print(f"c3 [{mode}] B=8 1024^2: max abs err of image 0 vs the fp64 golden {e0:.3e}; image alone vs in batch {d:.3e}")
+    assert e0 < BF16_ABS_BOUND[mode] and d < BF16_ABS_BOUND[mode]
+    # the images of the batch are different images (seeds 1000..1007): a stuck batch index would show here
+    assert float(np.abs(yn[1] - yn[0]).max()) > 0.1
+    m.close()
+
+
+def test_c5_2048_fp32_equivalent_against_golden(gpu):
+    """configs[4] geometry, B=1, in the parity-graded arithmetic: every 32nd pixel + global statistics of the fp32 restatement."""
+    import torch
+    cb, m = _full_model("f32_split3", 1, 2048)
+    k = np.load(os.path.join(GOLD, "model_2048.npz"))
+    x = torch.from_numpy(cb.synth_input(1, 2048, 2048)).cuda()
+    y = m.forward_logits(x).cpu().numpy().astype(np.float64)
+    ref = k["m2048_full_ref_s32"].astype(np.float64)
+    err = np.abs(y[:, :, ::32, ::32] - ref)
+    assert ((err <= 1e-3) | (err <= 1e-2 * np.abs(ref))).all(), f"max abs err {err.max():.3e}"
+    st = k["m2048_full_ref_stats"]
+    assert abs(y.sum() - st[0]) <= 2e-4 * st[1] and abs(np.abs(y).sum() - st[1]) <= 2e-4 * st[1]
+    assert abs(y.min() - st[2]) <= 1e-3 and abs(y.max() - st[3]) <= 1e-3
+    print(f"2048x2048 Swin-L [f32_split3]: max abs err on the strided fp32 golden {err.max():.2e}")
+    m.close()
+
+
+@pytest.mark.parametrize("mode", ["bf16_operands", "bf16"])
+def test_c5_batch4_2048_bf16(gpu, mode):
+    """configs[4]: B=4, 2048x2048 in the bf16 modes: finite, repeatable, image 0 bounded against the golden, batch independence."""
+    import torch
+    cb, m = _full_model(mode, 4, 2048)
+    k = np.load(os.path.join(GOLD, "model_2048.npz"))
+    x = torch.from_numpy(cb.synth_input(4, 2048, 2048)).cuda()
+    y = m.forward_logits(x)
+    assert torch.isfinite(y).all() and torch.equal(y, m.forward_logits(x))
+    yn = y.cpu().numpy().astype(np.float64)
+    e0 = float(np.abs(yn[0, :, ::32, ::32] - k["m2048_full_ref_s32"][0]).max())
+    d = float(np.abs(m.forward_logits(x[3:4]).cpu().numpy().astype(np.float64)[0] - yn[3]).max())
+    print(f"c5 [{mode}] B=4 2048^2: max abs err of image 0 vs the fp32 golden {e0:.3e}; image alone vs in batch {d:.3e}")
+    assert e0 < BF16_ABS_BOUND[mode] and d < BF16_ABS_BOUND[mode]
+    m.close()
+
+
+@pytest.mark.parametrize("compute", ["f32_split3", "bf16"])
+def test_two_processes_two_handles_bit_equal(gpu, tmp_path, compute):
+    """The N>1 path of the PRODUCT: bench.py's launcher starts 2 ranks (own process, own handle, device LOCAL_RANK % ndev = 0
+    here), each runs its shard of a 3-image global batch through libbirefnet_hip; the concatenation equals ONE process running
+    the three images one by one, bit for bit (images are independent units; no float atomics; same plan for the same shape)."""
+    import bench
+    import candle_birefnet_amd as cb
+    tag, gb = "m96_d2222_ref_b2", 3
+    rc = bench.launch_ranks(2, [sys.executable, os.path.join(HERE, "_shard_worker.py"), str(tmp_path), tag, str(gb), compute], timeout=900)
+    assert rc == 0
+    ys = np.concatenate([np.load(tmp_path / f"rank{r}.npy") for r in range(2)], 0)
+    depths, S, _, mode = G.MODEL_CASES[tag]
+    cfg = cb.BiRefNetConfig(deform_mode=mode)
+    cfg.swin.depths = list(depths)
+    w = cb.synth_weights(cb.birefnet_weight_spec(cfg), seed=42)
+    m = cb.BiRefNet.new(cfg, cb.VarBuilder.from_tensors(w), compute=compute)
+    # rank 0 ran images [0,2) as one batch of 2, rank 1 image 2 alone: reproduce exactly those calls in this process
+    x = cb.synth_input(gb, S, S)
+    y1 = np.concatenate([m.forward_logits(x[0:2]), m.forward_logits(x[2:3])], 0)
+    np.testing.assert_array_equal(ys, y1)
+    m.close()

@@ -98,15 +98,18 @@ def test_error_paths(gpu):
     m.close()
 
 
-def test_bf16_operand_mode_is_informational(gpu):
-    """BASELINE configs[2-4] arithmetic: bf16 GEMM operands.  Not a parity mode (the fp32 gate does not apply); its
-    error against the fp64 golden is bounded and reported."""
+@pytest.mark.parametrize("mode,bound", [("bf16_operands", 5e-2), ("bf16", 1e-1)])
+@pytest.mark.parametrize("tag", ["m128_full_ref", "m64_d2222_def", "m96_d2222_ref_b2"])
+def test_bf16_modes_are_informational(gpu, mode, bound, tag):
+    """BASELINE configs[2-4] arithmetic: bf16 GEMM operands (fp32 storage) and the bf16-storage mode.  Not parity modes (the
+    fp32 gate does not apply); their error against the fp64 golden is bounded and reported; repeatable bit for bit."""
     import candle_birefnet_amd as cb
     k = np.load(os.path.join(GOLD, "models_small.npz"))
-    cfg, w, x = G.model_case("m128_full_ref")
-    m = cb.BiRefNet.new(cfg, cb.VarBuilder.from_tensors(w), compute="bf16_operands")
+    cfg, w, x = G.model_case(tag)
+    m = cb.BiRefNet.new(cfg, cb.VarBuilder.from_tensors(w), compute=mode)
     y = m.forward_logits(x)
-    e = float(np.abs(y.astype(np.float64) - k["m128_full_ref"]).max())
-    print(f"bf16_operands: max abs err vs golden(fp64) {e:.2e}")
-    assert np.isfinite(y).all() and e < 5e-2
+    e = float(np.abs(y.astype(np.float64) - k[tag]).max())
+    print(f"{mode} {tag}: max abs err vs golden(fp64) {e:.2e} (|logit| max {np.abs(k[tag]).max():.2f})")
+    assert np.isfinite(y).all() and e < bound
+    np.testing.assert_array_equal(m.forward_logits(x), y)
     m.close()

@@ -237,3 +237,62 @@ def test_split_conv_exact_and_repeatable(gpu, mode):
             assert wrong == 0, f"{wrong} wrong elements (max |err| {np.abs(y - ref).max()})"
     finally:
         ops.set_compute("f32")
+
+
+# ---- compute mode BRN_BF16 (kernels/gemm_bf16.hip): bf16 operands in HBM, fp32 accumulation ------------------------------
+def _bf16_round(a):
+    """round-to-nearest-even fp32 -> bf16 -> fp32, as the library rounds operands (weights at load, activations at the edge)"""
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(torch.bfloat16).to(torch.float64).numpy()
+
+
+@pytest.mark.parametrize("M,K,N", [(300, 192, 576), (1000, 64, 512), (129, 768, 200), (64, 32, 16), (5000, 384, 1536), (7, 96, 130),
+                                   (4096, 3072, 768), (513, 160, 64), (33000, 192, 192)])
+@pytest.mark.parametrize("act", [None, "gelu_erf"])
+def test_linear_bf16_mode(gpu, M, K, N, act):
+    """the linear entry keeps y and the residual fp32 in this mode, so the reference is EXACT up to fp32 accumulation order:
+    operands rounded to bf16, products and sums in fp64.  K % 64 == 32 (the zero-page K tail), ragged M / N, split-K free."""
+    from candle_birefnet_amd import ops
+    x, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, std=K ** -0.5), rnd(N, seed=3), rnd(M, N, seed=4)
+    ops.set_compute("bf16")
+    try:
+        y = ops.linear(x, w, b, act=act, residual=r)
+    finally:
+        ops.set_compute("f32")
+    ref = torch.from_numpy(_bf16_round(x) @ _bf16_round(w).T) + torch.from_numpy(b).double()
+    if act == "gelu_erf":
+        ref = F.gelu(ref)
+    ref = ref + torch.from_numpy(r).double()
+    _close(y, ref.numpy(), tol=2e-5)
+
+
+@pytest.mark.parametrize("B,C,H,W,O,k,p", [(2, 64, 16, 16, 256, 3, 1), (1, 64, 20, 12, 256, 7, 3), (1, 96, 9, 11, 64, 3, 1), (1, 480, 12, 12, 64, 3, 1),
+                                           (1, 64, 33, 17, 192, 3, 1), (2, 3456, 8, 8, 64, 3, 1), (1, 64, 24, 24, 16, 3, 1)])
+def test_conv2d_bf16_mode(gpu, B, C, H, W, O, k, p):
+    """implicit-GEMM conv on bf16 maps: zero padding through the zero page, Cin = 480 (K steps that straddle taps, K % 64 = 32),
+    ragged maps, the tall-K split-K plan (3456 x 9), N = 16 (scalar stores).  The output map is bf16: tolerance = one bf16 ulp."""
+    from candle_birefnet_amd import ops
+    x, w, b = rnd(B, C, H, W, seed=1), rnd(O, C, k, k, seed=2, std=(C * k * k) ** -0.5), rnd(O, seed=3, std=0.1)
+    ops.set_compute("bf16")
+    try:
+        y = ops.conv2d(x, w, b, padding=p, act="relu")
+    finally:
+        ops.set_compute("f32")
+    ref = F.relu(F.conv2d(torch.from_numpy(_bf16_round(x)), torch.from_numpy(_bf16_round(w)), torch.from_numpy(b).double(), padding=p)).numpy()
+    err = np.abs(np.asarray(y, np.float64) - ref)
+    assert (err <= 2.0 ** -8 * np.abs(ref) + 1e-6).all(), f"max abs err {err.max():.3e}"
+
+
+def test_conv2d_nan_stays_local(gpu):
+    """masked (zero-padded) taps are zeroed by a bit mask / zero page, not by 0 * x: a non-finite input pixel spreads
+    only over its receptive field, like candle's conv2d; before, Inf at pixel (0,0) turned every border output into NaN."""
+    from candle_birefnet_amd import ops
+    x, w = rnd(1, 64, 12, 12, seed=1), rnd(32, 64, 3, 3, seed=2, std=0.05)
+    x[0, 3, 0, 0] = np.inf
+    for mode in ("f32", "f32_split3", "f32_split2", "bf16"):
+        ops.set_compute(mode)
+        try:
+            y = np.asarray(ops.conv2d(x, w, None, padding=1))
+        finally:
+            ops.set_compute("f32")
+        bad = ~np.isfinite(y)
+        assert bad[:, :, :2, :2].any() and not bad[:, :, 2:, :].any() and not bad[:, :, :, 2:].any(), mode

@@ -65,3 +65,31 @@ def test_native_loader_parses_then_needs_a_device_or_a_tensor(tmp_path):
         assert st == _ffi.BRN_ERR_MISSING_TENSOR and "bb." in msg
     else:
         assert st == _ffi.BRN_ERR_NO_DEVICE
+
+
+def _raw_file(path, hdr: bytes, data: bytes):
+    path.write_bytes(len(hdr).to_bytes(8, "little") + hdr + data)
+    return path
+
+
+def test_native_loader_rejects_crafted_headers(tmp_path):
+    """The header is untrusted input: wrapped shapes, duplicate names, overlapping tensors, unbalanced or trailing JSON are refused
+    before any size derived from them reaches a memcpy (the safetensors crate rejects the same files)."""
+    from candle_birefnet_amd import _ffi
+    # 2^62 x 4 elements of 4 bytes wraps to 0 modulo 2^64 == (b1 - b0): must not pass as an empty tensor
+    st, msg = _create_from_file(_raw_file(tmp_path / "wrap.safetensors", b'{"a":{"dtype":"F32","shape":[4611686018427387904,4],"data_offsets":[0,0]}}', b""))
+    assert st in (_ffi.BRN_ERR_SHAPE, _ffi.BRN_ERR_INVALID_ARG) and ("impossible shape" in msg or "out of range" in msg), msg
+    st, msg = _create_from_file(_raw_file(tmp_path / "wrap2.safetensors", b'{"a":{"dtype":"F32","shape":[1073741824,1073741824,4],"data_offsets":[0,0]}}', b""))
+    assert st == _ffi.BRN_ERR_SHAPE and "impossible shape" in msg, msg
+    st, msg = _create_from_file(_raw_file(tmp_path / "dup.safetensors",
+                                          b'{"a":{"dtype":"F32","shape":[1],"data_offsets":[0,4]},"a":{"dtype":"F32","shape":[1],"data_offsets":[4,8]}}', b"\0" * 8))
+    assert st == _ffi.BRN_ERR_INVALID_ARG and "appears twice" in msg, msg
+    st, msg = _create_from_file(_raw_file(tmp_path / "overlap.safetensors",
+                                          b'{"a":{"dtype":"F32","shape":[2],"data_offsets":[0,8]},"b":{"dtype":"F32","shape":[2],"data_offsets":[4,12]}}', b"\0" * 12))
+    assert st == _ffi.BRN_ERR_INVALID_ARG and "overlap" in msg, msg
+    st, msg = _create_from_file(_raw_file(tmp_path / "open.safetensors", b'{"a":{"dtype":"F32","shape":[1],"data_offsets":[0,4]}', b"\0" * 4))
+    assert st == _ffi.BRN_ERR_INVALID_ARG, msg
+    st, msg = _create_from_file(_raw_file(tmp_path / "trail.safetensors", b'{"a":{"dtype":"F32","shape":[1],"data_offsets":[0,4]}} x', b"\0" * 4))
+    assert st == _ffi.BRN_ERR_INVALID_ARG and "after the header" in msg, msg
+    st, msg = _create_from_file(_raw_file(tmp_path / "meta.safetensors", b'{"__metadata__":{"k":["}",{"q":"]"}]},"a":{"dtype":"F32","shape":[1],"data_offsets":[0,4]}}   ', b"\0" * 4))
+    assert st in (_ffi.BRN_ERR_MISSING_TENSOR, _ffi.BRN_ERR_NO_DEVICE), msg      # parsed; stops later for want of tensors / a device
