@@ -55,7 +55,7 @@ GemmPlan plan_gemm(int M, int N, int K, int planes = 0);   // planes: bf16 plane
 // ws: plan.ws_floats floats of scratch when plan.splitk > 1.  Returns the hipError_t of the launch(es).
 hipError_t launch_gemm(const GemmParams& p, const GemmPlan& plan, float* ws, hipStream_t s);
 
-// bf16-storage mode: plan + launch (kernels/gemm_bf16.hip).  cfg: 0 / 2 = 128x128, 1 / 3 = 128x64 block tile (K step 64 / 32)
+// bf16-storage mode: plan + launch (kernels/gemm_bf16.hip).  cfg: 0 = 128x128, 1 = 128x64, 2 = 256x256, 3 = 256x192 block tile
 GemmPlan plan_gemm_bf16(int M, int N, int K);
 hipError_t launch_gemm_bf16(const GemmParams& p, const GemmPlan& plan, float* ws, hipStream_t s);
 
