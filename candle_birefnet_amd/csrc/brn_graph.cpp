@@ -5,6 +5,7 @@
 #include "brn_host.h"
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 
 namespace brn {
 
@@ -85,9 +86,20 @@ void run_gemm(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* C, 
         run_gemm_bf16(c, w, p, FAM_GEMM_DENSE);
         return;
     }
-    GemmPlan pl = plan_gemm(M, w.N, w.K, w.wp ? w.planes : 0);
-    if (a_planes || c_planes) {
-        // P2 operands exist only on the warp-specialised 2-plane kernel; a P2 output cannot go through the split-K reduce pass
+    GemmParams p{};
+    p.A = A; p.W = w.w; p.C = C; p.M = M; p.N = w.N; p.K = w.K; p.mode = GEMM_DENSE; p.lda = lda;
+    fill_epilogue(p, w);
+    p.bbias = bbias; p.bbias_rows = bbias_rows > 0 ? bbias_rows : 1;
+    p.R = R; p.ldr = ldr; p.r_coff = r_coff; p.ldc = ldc; p.c_coff = c_coff;
+    p.a_planes = a_planes; p.c_planes = c_planes;
+    // A already split by its producer (P layout): the LDS-DMA plane kernel (kernels/gemm_planes.hip), when the shape allows
+    // (opt-in, BRN_PLANES_KERNEL=1: at batch 1 it measured 10-12 % SLOWER per forward than the warp-specialised kernel in both
+    // split modes — MFMA utilisation 0.40 vs 0.44, profiles/r02_pmc_sq_c2_planes.csv — see DESIGN.md 3.1c)
+    static const bool planes_on = getenv("BRN_PLANES_KERNEL") && atoi(getenv("BRN_PLANES_KERNEL")) != 0;
+    const bool planes_kernel = planes_on && a_planes && gemm_planes_eligible(p);
+    GemmPlan pl = planes_kernel ? plan_gemm_planes(M, w.N, w.K, w.planes, c_planes != 0) : plan_gemm(M, w.N, w.K, w.wp ? w.planes : 0);
+    if (!planes_kernel && (a_planes || c_planes)) {
+        // otherwise P operands exist only on the warp-specialised kernel; a P output cannot go through the split-K reduce pass
         if (!(w.wp && (w.planes == 2 || w.planes == 3))) fail(BRN_ERR_INVALID_ARG, "P activation layout outside the split modes");
         pl.cfg = 0;
         if (c_planes) { pl.splitk = 1; pl.ws_floats = 0; }
@@ -96,16 +108,11 @@ void run_gemm(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* C, 
     float* ws = pl.ws_floats ? c.arena->alloc(pl.ws_floats) : nullptr;
     c.arena->release(mk);          // scratch is dead as soon as the reduce pass has been enqueued (in-order stream)
     if (c.dry) return;
-    GemmParams p{};
-    p.A = A; p.W = w.w; p.C = C; p.M = M; p.N = w.N; p.K = w.K; p.mode = GEMM_DENSE; p.lda = lda;
-    fill_epilogue(p, w);
-    p.bbias = bbias; p.bbias_rows = bbias_rows > 0 ? bbias_rows : 1;
-    p.R = R; p.ldr = ldr; p.r_coff = r_coff; p.ldc = ldc; p.c_coff = c_coff;
-    p.a_planes = a_planes; p.c_planes = c_planes;
     const double flop = 2.0 * M * (double)w.N * w.K;
     const double bytes = 4.0 * ((double)M * w.K + (double)w.N * w.K + (double)M * w.N * (R ? 2 : 1));
     Bracket b(c, FAM_GEMM_DENSE, flop, bytes, M, w.N, w.K);
-    BRN_LAUNCH(launch_gemm(p, pl, ws, c.stream));
+    if (planes_kernel) BRN_LAUNCH(launch_gemm_planes(p, pl, ws, c.stream));
+    else BRN_LAUNCH(launch_gemm(p, pl, ws, c.stream));
 }
 
 void run_conv(Ctx& c, const GemmW& w, const Map& in, const Map& out, const float* om, int om_ld, int om_mask_off, int c_f32) {
@@ -279,8 +286,10 @@ void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int 
         if (!st.blocks.empty()) {
             const SwinBlockW& b0 = st.blocks[0];
             const int np = b0.qkv.planes;
-            // (3 planes = rows 1.5x as long: measured 2 % SLOWER per forward in f32_split3, whose kernel is not staging-bound: 2 only)
-            if (np == 2 && b0.qkv.wp && b0.proj.wp && b0.fc1.wp && b0.fc2.wp && C % 32 == 0 && hidden % 32 == 0) stage_pl = np;
+            // (3 planes = rows 1.5x as long: measured 2 % SLOWER per forward in f32_split3 with the warp-specialised kernel, and the
+            // LDS-DMA plane kernel, kernels/gemm_planes.hip, which needs P3 input, did not beat it at batch 1: 2 planes only by default)
+            static const bool planes_on = getenv("BRN_PLANES_KERNEL") && atoi(getenv("BRN_PLANES_KERNEL")) != 0;
+            if ((np == 2 || (np == 3 && planes_on)) && b0.qkv.wp && b0.proj.wp && b0.fc1.wp && b0.fc2.wp && C % 32 == 0 && hidden % 32 == 0) stage_pl = np;
         }
         const int ldx = stage_pl ? C * stage_pl / 2 : C, ldh = stage_pl ? hidden * stage_pl / 2 : hidden;
         // compute mode BRN_BF16: x (the residual stream) stays fp32; every GEMM operand (xn, qkv, att, hid, pm) is bf16
@@ -302,7 +311,7 @@ void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int 
         // stage output = norm_i(x_out), pre-downsample (swin.rs:591,784-789); written into its consumer's window
         size_t off = 0, off2 = 0;
         float* pm = nullptr;
-        const int pm_pl = (st.has_down && st.reduction.wp && st.reduction.planes == 2 && (4 * C) % 32 == 0) ? 2 : 0;
+        const int pm_pl = (st.has_down && st.reduction.wp && (st.reduction.planes == 2 || (st.reduction.planes == 3 && stage_pl == 3)) && (4 * C) % 32 == 0) ? st.reduction.planes : 0;
         const int ldpm = pm_pl ? 4 * C * pm_pl / 2 : 4 * C;
         if (st.has_down) pm = c.act_alloc((size_t)total(i + 1) * ldpm);
         for (int k = 0; k < nin; ++k) {

@@ -59,6 +59,11 @@ hipError_t launch_gemm(const GemmParams& p, const GemmPlan& plan, float* ws, hip
 GemmPlan plan_gemm_bf16(int M, int N, int K);
 hipError_t launch_gemm_bf16(const GemmParams& p, const GemmPlan& plan, float* ws, hipStream_t s);
 
+// split modes with A already in the P layout (kernels/gemm_planes.hip): LDS-DMA staged, persistent, no splitting wave
+bool gemm_planes_eligible(const GemmParams& p);
+GemmPlan plan_gemm_planes(int M, int N, int K, int planes, bool c_planes);
+hipError_t launch_gemm_planes(const GemmParams& p, const GemmPlan& plan, float* ws, hipStream_t s);
+
 #ifdef BRN_DIAG_BUILD
 hipError_t launch_mfma_valu_probe(int blocks, int iters, int mode, float* sink, hipStream_t s);
 hipError_t launch_lds_mfma_probe(int blocks, int iters, int np, int variant, float* sink, hipStream_t s);
