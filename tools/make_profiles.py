@@ -78,12 +78,12 @@ def main():
                 w.writerow([k, n, f"{f_kb:.1f}", f"{w_kb:.1f}", f"{rgb:.3f}", f"{wgb:.3f}"])
                 if "gemm" in k and "reduce" not in k:
                     gem["gemm_family_dispatches"] += n; gem["hbm_read_gb_x2corrected"] += rgb; gem["hbm_write_gb"] += wgb
-        json.dump(gem, open(os.path.join(root, f"{a.tag}_gemm_traffic_{a.suffix.split('_')[-1]}.json"), "w"))
+        json.dump(gem, open(os.path.join(root, f"{a.tag}_gemm_traffic_{a.suffix}.json"), "w"))
         print("wrote", out, gem)
     if a.launches:
         shutil.copy(a.launches, os.path.join(root, f"{a.tag}_launches_{a.suffix}.csv"))
     if a.bench:
-        shutil.copy(a.bench, os.path.join(root, f"{a.tag}_bench_{a.suffix.split('_')[-1]}.json"))
+        shutil.copy(a.bench, os.path.join(root, f"{a.tag}_bench_{a.suffix}.json"))
 
 
 if __name__ == "__main__":
