@@ -668,12 +668,13 @@ brn_status brn_window_attention_forward(const float* x, int B, int H, int W, int
                                         const float* rel_table, float* y, brn_mem loc, int device, void* stream) {
     return guarded([&] {
         if (!x || !qkv_w || !qkv_b || !proj_w || !proj_b || !rel_table || !y) fail(BRN_ERR_INVALID_ARG, "null argument");
-        if (window_size != 12 || heads < 1 || C != heads * 32 || !(shift == 0 || shift == 6))
-            fail(BRN_ERR_INVALID_ARG, "window attention needs window_size 12, head_dim 32, shift 0 or 6");
+        if (!(window_size == 12 || window_size == 7) || heads < 1 || C != heads * 32 || !(shift == 0 || shift == window_size / 2))
+            fail(BRN_ERR_INVALID_ARG, "window attention needs window_size 12 or 7, head_dim 32, shift 0 or window_size / 2");
+        if (window_size == 7 && g_op_planes != 0) fail(BRN_ERR_INVALID_ARG, "window_size 7 runs in compute mode f32 only");
         ensure_device(device);
         DeviceOwner own;
         // reuse the model's weight builder through a one-block table
-        const int T = 23 * 23;
+        const int T = (2 * window_size - 1) * (2 * window_size - 1);
         int64_t s_qw[2] = {3 * C, C}, s_qb[1] = {3 * C}, s_pw[2] = {C, C}, s_pb[1] = {C}, s_t[2] = {T, heads};
         SwinBlockW bk;
         bk.heads = heads;
@@ -689,7 +690,7 @@ brn_status brn_window_attention_forward(const float* x, int B, int H, int W, int
         Staging st(stream, loc);
         const float* dx = st.in(x, (size_t)B * H * W * C);
         float* dy = st.out(y, (size_t)B * H * W * C);
-        with_arena((hipStream_t)stream, [&](Ctx& c) { swin_attention(c, bk, dx, B, H, W, C, shift, dy, nullptr); });
+        with_arena((hipStream_t)stream, [&](Ctx& c) { swin_attention(c, bk, dx, B, H, W, C, shift, dy, nullptr, window_size); });
         st.finish();
     });
 }

@@ -161,9 +161,12 @@ void run_conv(Ctx& c, const GemmW& w, const Map& in, const Map& out, const float
     BRN_LAUNCH(launch_gemm(p, pl, ws, c.stream));
 }
 
-void run_conv_nchw(Ctx& c, const GemmW& w, const float* x, int B, int Hin, int Win, const Map& out) {
-    const int Hout = (Hin + 2 * w.pad - w.dil * (w.kh - 1) - 1) / w.stride + 1;
-    const int Wout = (Win + 2 * w.pad - w.dil * (w.kw - 1) - 1) / w.stride + 1;
+void run_conv_nchw(Ctx& c, const GemmW& w, const float* x, int B, int Hin, int Win, const Map& out, bool pad_to_stride) {
+    int Hout = (Hin + 2 * w.pad - w.dil * (w.kh - 1) - 1) / w.stride + 1;
+    int Wout = (Win + 2 * w.pad - w.dil * (w.kw - 1) - 1) / w.stride + 1;
+    // PatchEmbed (swin.rs:696-702) first pads the image with zeros on the right / bottom to a multiple of the patch: for a
+    // k == stride, pad 0 conv that is the ceil-mode output size, and the gather loader already returns 0 beyond the border
+    if (pad_to_stride && w.kh == w.stride && w.kw == w.stride && w.pad == 0 && w.dil == 1) { Hout = (Hin + w.stride - 1) / w.stride; Wout = (Win + w.stride - 1) / w.stride; }
     if (out.H != Hout || out.W != Wout || out.B != B || out.C != w.N)
         fail(BRN_ERR_INVALID_ARG, "conv(nchw) output map mismatch");
     const int M = B * Hout * Wout;
@@ -212,7 +215,7 @@ void swin_stage_dims(int H, int W, int patch, int hs[4], int ws[4]) {
 // The attention half of a block for `nin` token sets that share the weights (the full- and half-scale backbone passes
 // of birefnet.rs:416,426 are run as ONE pass over concatenated token rows: every per-token op sees M = M_full + M_half).
 static void swin_attention_multi(Ctx& c, const SwinBlockW& blk, const float* xn, int B, int nin, const int* hs, const int* wsz, int C,
-                                 int shift, float* y, const float* residual, int p2 = 0) {
+                                 int shift, float* y, const float* residual, int p2 = 0, int window = 12) {
     const size_t mk = c.arena->mark();
     int M = 0;
     for (int k = 0; k < nin; ++k) M += B * hs[k] * wsz[k];
@@ -230,14 +233,16 @@ static void swin_attention_multi(Ctx& c, const SwinBlockW& blk, const float* xn,
             p.qkv = c.at(qkv, off * 3 * C); p.qkv_bias = blk.qkv.bias; p.rel_table = blk.rel_table; p.out = c.at(att, off * ldp);
             p.io_bf16 = c.bf16;
             p.B = B; p.H = hs[k]; p.W = wsz[k]; p.C = C; p.heads = blk.heads;
-            p.Hp = roundup(hs[k], 12); p.Wp = roundup(wsz[k], 12);   // swin.rs:359-360
+            p.Hp = roundup(hs[k], window); p.Wp = roundup(wsz[k], window);   // swin.rs:359-360
+            p.ws = window;
             p.shift = shift; p.scale = 1.0f / sqrtf(32.0f);          // head_dim^-0.5 (swin.rs:134)
-            p.planes = (!c.bf16 && (blk.qkv.planes == 2 || blk.qkv.planes == 1)) ? blk.qkv.planes : 0;
+            p.planes = (!c.bf16 && window == 12 && (blk.qkv.planes == 2 || blk.qkv.planes == 1)) ? blk.qkv.planes : 0;
             p.out_planes = p2;
-            nwin += (double)B * (p.Hp / 12) * (p.Wp / 12) * blk.heads;
+            nwin += (double)B * (p.Hp / window) * (p.Wp / window) * blk.heads;
             off += (size_t)B * hs[k] * wsz[k];
         }
-        Bracket b(c, FAM_ATTENTION, nwin * 2.0 * 2.0 * 144 * 144 * 32, (double)c.esz() * ((double)M * 4 * C), M, C, shift);
+        const double ntok = (double)window * window;
+        Bracket b(c, FAM_ATTENTION, nwin * 2.0 * 2.0 * ntok * ntok * 32, (double)c.esz() * ((double)M * 4 * C), M, C, shift);
         BRN_LAUNCH(launch_window_attention2(ps[0], nin > 1 ? &ps[1] : nullptr, c.stream));
     }
     // swin.rs:310 (+ shortcut, swin.rs:406); the residual stream y / residual stays fp32 in every mode
@@ -246,8 +251,8 @@ static void swin_attention_multi(Ctx& c, const SwinBlockW& blk, const float* xn,
 }
 
 void swin_attention(Ctx& c, const SwinBlockW& blk, const float* xn, int B, int H, int W, int C, int shift, float* y,
-                    const float* residual) {
-    swin_attention_multi(c, blk, xn, B, 1, &H, &W, C, shift, y, residual);
+                    const float* residual, int window) {
+    swin_attention_multi(c, blk, xn, B, 1, &H, &W, C, shift, y, residual, 0, window);
 }
 
 void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int B) {
@@ -266,7 +271,7 @@ void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int 
         size_t off = 0;
         for (int k = 0; k < nin; ++k) {
             Map tm; tm.p = t + off * E; tm.B = B; tm.H = hs[k][0]; tm.W = wsz[k][0]; tm.C = E; tm.ld = E; tm.coff = 0;
-            run_conv_nchw(c, w.patch_proj, ins[k].img, B, ins[k].H, ins[k].W, tm);
+            run_conv_nchw(c, w.patch_proj, ins[k].img, B, ins[k].H, ins[k].W, tm, true);
             off += rows(k, 0);
         }
         run_layernorm(c, w.patch_norm, t, total(0), E, x, E, 0);
@@ -289,7 +294,7 @@ void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int 
             // (3 planes = rows 1.5x as long: measured 2 % SLOWER per forward in f32_split3 with the warp-specialised kernel, and the
             // LDS-DMA plane kernel, kernels/gemm_planes.hip, which needs P3 input, did not beat it at batch 1: 2 planes only by default)
             static const bool planes_on = getenv("BRN_PLANES_KERNEL") && atoi(getenv("BRN_PLANES_KERNEL")) != 0;
-            if ((np == 2 || (np == 3 && planes_on)) && b0.qkv.wp && b0.proj.wp && b0.fc1.wp && b0.fc2.wp && C % 32 == 0 && hidden % 32 == 0) stage_pl = np;
+            if (w.window == 12 && (np == 2 || (np == 3 && planes_on)) && b0.qkv.wp && b0.proj.wp && b0.fc1.wp && b0.fc2.wp && C % 32 == 0 && hidden % 32 == 0) stage_pl = np;
         }
         const int ldx = stage_pl ? C * stage_pl / 2 : C, ldh = stage_pl ? hidden * stage_pl / 2 : hidden;
         // compute mode BRN_BF16: x (the residual stream) stays fp32; every GEMM operand (xn, qkv, att, hid, pm) is bf16
@@ -303,7 +308,7 @@ void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int 
             // would split out while staging), so the GEMMs' staging waves only copy
             const int p2 = stage_pl;
             run_layernorm(c, bk.norm1, x, M, C, xn, ldx, 0, p2, yb);                  // swin.rs:355
-            swin_attention_multi(c, bk, xn, B, nin, hh, ww, C, shift, x, x, p2);      // x = shortcut + attn (swin.rs:406)
+            swin_attention_multi(c, bk, xn, B, nin, hh, ww, C, shift, x, x, p2, w.window);   // x = shortcut + attn (swin.rs:406)
             run_layernorm(c, bk.norm2, x, M, C, xn, ldx, 0, p2, yb);                  // swin.rs:407
             run_gemm(c, bk.fc1, xn, M, ldx, hid, ldh, 0, nullptr, 0, 0, nullptr, 0, p2, p2);   // fc1 + gelu_erf (swin.rs:104-105)
             run_gemm(c, bk.fc2, hid, M, ldh, x, C, 0, x, C, 0, nullptr, 0, p2, 0, yb, yb);     // x + fc2(...) (swin.rs:106,407)

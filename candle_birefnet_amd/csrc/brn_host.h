@@ -205,7 +205,7 @@ void run_gemm(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* C, 
               int c_f32 = 0, int r_f32 = 0 /* compute mode BRN_BF16 only: C written / R read as fp32 (the residual stream) */);
 void run_conv(Ctx& c, const GemmW& w, const Map& in, const Map& out, const float* om = nullptr, int om_ld = 0, int om_mask_off = 0,
               int c_f32 = 0);
-void run_conv_nchw(Ctx& c, const GemmW& w, const float* x_nchw, int B, int Hin, int Win, const Map& out);
+void run_conv_nchw(Ctx& c, const GemmW& w, const float* x_nchw, int B, int Hin, int Win, const Map& out, bool pad_to_stride = false);
 void run_layernorm(Ctx& c, const LNW& ln, const float* x, int rows, int ldx, float* y, int ldy, int y_coff, int y_planes = 0, int y_bf16 = 0);
 void run_resize(Ctx& c, const Map& in, const Map& out);
 
@@ -217,7 +217,7 @@ struct SwinIn { const float* img; int H, W; const Map* outs; };   // one backbon
 void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int B);
 // the attention half of one block (swin.rs:356-403), x is the norm1 output, y = proj(attn) (no residual) or += residual
 void swin_attention(Ctx& c, const SwinBlockW& blk, const float* xn, int B, int H, int W, int C, int shift,
-                    float* y, const float* residual);
+                    float* y, const float* residual, int window = 12);
 void decblk_forward(Ctx& c, const DecBlkW& w, const Map& in, const Map& out, int deform_mode);
 void decoder_forward(Ctx& c, const Model& m, const float* img_nchw, int B, int H, int W, const Map& x1, const Map& x2,
                      const Map& x3, const Map& d4 /* [.., 3456] with [0:3072) = squeezed x4 */, float* out, int apply_sigmoid);

@@ -96,6 +96,7 @@ struct WindowAttnParams {
     float scale;          // head_dim^-0.5
     int planes;           // 0: fp32 MFMA kernel (modes f32, f32_split3); 2 / 1: bf16-split kernel (f32_split2 / bf16_operands)
     int out_planes;       // 2: write `out` in the P2 layout (kernels/split_planes.h) for the proj GEMM; 0: fp32
+    int ws;               // window side: 12 (0 = 12) or 7 (Swin-T / S: fp32 kernel only)
     int io_bf16;          // 1: qkv and out are bf16 matrices (compute mode BRN_BF16; qkv_bias / rel_table stay fp32)
 };
 hipError_t launch_window_attention(const WindowAttnParams& p, hipStream_t s);

@@ -209,7 +209,8 @@ static GemmW get_linear(const WeightTable& wt, const std::string& p, int N, int 
 
 // ---- Swin (swin.rs:725-764) -----------------------------------------------------------------------------------------
 void build_swin_weights(const WeightTable& wt, const std::string& pre, const brn_config& cfg, DeviceOwner& own, SwinW& out) {
-    if (cfg.window_size != 12) fail(BRN_ERR_INVALID_ARG, "window_size %d unsupported: the attention kernel is built for 12 (Swin-B/L, swin.rs:60,74)", cfg.window_size);
+    if (cfg.window_size != 12 && cfg.window_size != 7)
+        fail(BRN_ERR_INVALID_ARG, "window_size %d unsupported: the attention kernels are built for 12 (Swin-B / L, swin.rs:60,74) and 7 (Swin-T / S, swin.rs:32,46)", cfg.window_size);
     if (cfg.patch_size < 1 || cfg.in_channels < 1) fail(BRN_ERR_INVALID_ARG, "bad patch_size/in_channels");
     out.embed_dim = cfg.embed_dim; out.window = cfg.window_size; out.patch = cfg.patch_size; out.in_ch = cfg.in_channels;
     const int E = cfg.embed_dim, P = cfg.patch_size, IC = cfg.in_channels;

@@ -36,13 +36,18 @@ constexpr int ATT_THREADS = 192;   // 3 waves, 3 query tiles each
 // Both kernels take TWO geometries (the full- and the half-scale map of a co-batched backbone pass, same C / heads / shift):
 // blocks [0, nblk0) work on pa, the rest on pb — one launch, one ramp and one tail instead of two (the half-scale launch alone
 // fills a fifth of the CU slots).  nblk0 = all blocks when there is only one map.
+// WSZ = window side: 12 (Swin-B / L, swin.rs:60,74) or 7 (Swin-T / S, swin.rs:32,46); head_dim is 32 in all four configurations.
+// A window holds WSZ^2 tokens = NT16 key / query tiles of 16; the tail of the last tile (49 -> 64) is dummy: zero K / V rows, scores
+// forced to -3e38 so that they leave the softmax, queries never stored.
+template <int WSZ>
 __global__ void __launch_bounds__(ATT_THREADS) window_attention_f32_kernel(const WindowAttnParams pa, const WindowAttnParams pb, const int nblk0) {
+    constexpr int WS = WSZ, NTOK = WSZ * WSZ, NT16 = (NTOK + 15) / 16, NPADTOK = NT16 * 16;
     const bool second = (int)blockIdx.x >= nblk0;
     const WindowAttnParams& p = second ? pb : pa;
-    __shared__ __attribute__((aligned(16))) float Ks[NTOK * KV_LD];
-    __shared__ __attribute__((aligned(16))) float Vs[NTOK * KV_LD];
-    __shared__ int src_s[NTOK];   // source token offset (pixel index) or -1 for a pad token
-    __shared__ int rid_s[NTOK];   // SW-MSA region id of the token (swin.rs:608-629)
+    __shared__ __attribute__((aligned(16))) float Ks[NPADTOK * KV_LD];
+    __shared__ __attribute__((aligned(16))) float Vs[NPADTOK * KV_LD];
+    __shared__ int src_s[NPADTOK];   // source token offset (pixel index) or -1 for a pad token
+    __shared__ int rid_s[NPADTOK];   // SW-MSA region id of the token (swin.rs:608-629)
     __shared__ float tab_s[(2 * WS - 1) * (2 * WS - 1)];   // this head's column of relative_position_bias_table
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -63,17 +68,18 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_f32_kernel(const
         const int fh = ph < p.Hp - WS ? 0 : (ph < p.Hp - p.shift ? 1 : 2);   // h_slices / w_slices, swin.rs:608-617
         const int fw = pw < p.Wp - WS ? 0 : (pw < p.Wp - p.shift ? 1 : 2);
         rid_s[tid] = fh * 3 + fw;
-    }
+    } else if (tid < NPADTOK) { src_s[tid] = -1; rid_s[tid] = 0; }
     for (int i = tid; i < (2 * WS - 1) * (2 * WS - 1); i += ATT_THREADS) tab_s[i] = p.rel_table[head * ((2 * WS - 1) * (2 * WS - 1)) + i];
     __syncthreads();
 
     // ---- stage K and V of this (window, head) into LDS: 144 rows x 8 float4 each ----
-    for (int idx = tid; idx < NTOK * 8; idx += ATT_THREADS) {
+    for (int idx = tid; idx < NPADTOK * 8; idx += ATT_THREADS) {
         const int t = idx >> 3, c4 = (idx & 7) * 4;
         const int src = src_s[t];
         const float* kp = src >= 0 ? p.qkv + (long)src * C3 + C + head * HD + c4 : p.qkv_bias + C + head * HD + c4;
-        const f32x4 kv = *reinterpret_cast<const f32x4*>(kp);
-        const f32x4 vv = *reinterpret_cast<const f32x4*>(kp + C);
+        f32x4 kv = *reinterpret_cast<const f32x4*>(kp);
+        f32x4 vv = *reinterpret_cast<const f32x4*>(kp + C);
+        if (t >= NTOK) { kv = f32x4{0.f, 0.f, 0.f, 0.f}; vv = kv; }      // dummy tail of the last tile
         *reinterpret_cast<f32x4*>(Ks + t * KV_LD + c4) = kv;
         *reinterpret_cast<f32x4*>(Vs + t * KV_LD + c4) = vv;
     }
@@ -81,12 +87,13 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_f32_kernel(const
 
     const int li = lane & 15, g = lane >> 4;
 
-    for (int qt = wave; qt < 9; qt += 3) {
+    for (int qt = wave; qt < NT16; qt += 3) {
         const int qtok = qt * 16 + li;
         const int qsrc = src_s[qtok];
         const int qrid = rid_s[qtok];
         // relative position index (swin.rs:182-184): (qi-ki+11)*23 + (qj-kj+11) = qbase - (key + 11*(key/12))
-        const int qbase = (qtok / WS + WS - 1) * (2 * WS - 1) + (qtok % WS) + WS - 1;
+        const int qt_ = qtok < NTOK ? qtok : NTOK - 1;            // (dummy queries of the last tile compute on a valid row, never stored)
+        const int qbase = (qt_ / WS + WS - 1) * (2 * WS - 1) + (qt_ % WS) + WS - 1;
         // Q fragment: d = 8g .. 8g+7 of query row qtok, scaled before the product (swin.rs:278)
         float qf[8];
         {
@@ -97,9 +104,9 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_f32_kernel(const
             for (int e = 0; e < 4; ++e) { qf[e] = q0[e] * p.scale; qf[4 + e] = q1[e] * p.scale; }
         }
         // S^T = K . Q^T : 9 key tiles
-        f32x4 st[9];
+        f32x4 st[NT16];
 #pragma unroll
-        for (int kt = 0; kt < 9; ++kt) {
+        for (int kt = 0; kt < NT16; ++kt) {
             const float* kp = Ks + (kt * 16 + li) * KV_LD + g * 8;
             const f32x4 k0 = *reinterpret_cast<const f32x4*>(kp);
             const f32x4 k1 = *reinterpret_cast<const f32x4*>(kp + 4);
@@ -114,12 +121,14 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_f32_kernel(const
         // + relative position bias (swin.rs:284-285), + SW-MSA mask (swin.rs:288-297, value -100 swin.rs:651)
         float mx = -3.0e38f;
 #pragma unroll
-        for (int kt = 0; kt < 9; ++kt) {
+        for (int kt = 0; kt < NT16; ++kt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = kt * 16 + g * 4 + r;
-                float s = st[kt][r] + tab_s[qbase - key - 11 * (key / WS)];
+                const int kk = key < NTOK ? key : 0;
+                float s = st[kt][r] + tab_s[max(0, qbase - kk - (WS - 1) * (kk / WS))];
                 if (p.shift > 0) s += (rid_s[key] != qrid) ? -100.0f : 0.0f;
+                if (NTOK % 16 != 0 && key >= NTOK) s = -3.0e38f;
                 st[kt][r] = s;
                 mx = fmaxf(mx, s);
             }
@@ -128,7 +137,7 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_f32_kernel(const
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         float sum = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < 9; ++kt) {
+        for (int kt = 0; kt < NT16; ++kt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float e = __expf(st[kt][r] - mx);
@@ -141,7 +150,7 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_f32_kernel(const
         // O^T = V^T . P^T : two d tiles
         f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kt = 0; kt < 9; ++kt) {
+        for (int kt = 0; kt < NT16; ++kt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float* vp = Vs + (kt * 16 + g * 4 + r) * KV_LD + li;
@@ -151,7 +160,7 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_f32_kernel(const
             if (kt % 2 == 1) __builtin_amdgcn_sched_barrier(0);
         }
         // lane holds O^T[d = 16*dt + 4g + r][query = li]; softmax denominator applied here (swin.rs:300,303)
-        if (qsrc >= 0) {
+        if (qsrc >= 0 && qtok < NTOK) {
             const float inv = 1.0f / sum;
             if (p.out_planes == 3) {        // mode f32_split3: the proj GEMM reads the 3-plane P layout (rows 1.5x as long)
                 float* orow = p.out + (long)qsrc * (C + C / 2);
@@ -538,17 +547,22 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_bf16_kernel(cons
 }
 
 static hipError_t check_attention(const WindowAttnParams& p) {
-    if (p.C != p.heads * HD || p.Hp % WS || p.Wp % WS || p.Hp < p.H || p.Wp < p.W) return hipErrorInvalidValue;
-    if (!(p.shift == 0 || p.shift == WS / 2)) return hipErrorInvalidValue;
+    const int ws = p.ws ? p.ws : WS;
+    if (!(ws == 12 || ws == 7)) return hipErrorInvalidValue;
+    if (p.C != p.heads * HD || p.Hp % ws || p.Wp % ws || p.Hp < p.H || p.Wp < p.W) return hipErrorInvalidValue;
+    if (!(p.shift == 0 || p.shift == ws / 2)) return hipErrorInvalidValue;
+    if (ws != WS && (p.planes || p.out_planes || p.io_bf16)) return hipErrorInvalidValue;   // window 7 (Swin-T / S): the fp32 kernel only
     return hipSuccess;
 }
 hipError_t launch_window_attention2(const WindowAttnParams& p, const WindowAttnParams* p2, hipStream_t s) {
     if (check_attention(p) != hipSuccess) return hipErrorInvalidValue;
-    const int n0 = p.B * (p.Hp / WS) * (p.Wp / WS);
+    const int ws = p.ws ? p.ws : WS;
+    const int n0 = p.B * (p.Hp / ws) * (p.Wp / ws);
     int n1 = 0;
     if (p2) {
+        if ((p2->ws ? p2->ws : WS) != ws) return hipErrorInvalidValue;
         if (check_attention(*p2) != hipSuccess || p2->C != p.C || p2->heads != p.heads || p2->planes != p.planes || p2->out_planes != p.out_planes || p2->io_bf16 != p.io_bf16) return hipErrorInvalidValue;
-        n1 = p2->B * (p2->Hp / WS) * (p2->Wp / WS);
+        n1 = p2->B * (p2->Hp / ws) * (p2->Wp / ws);
     }
     if (p.out_planes && !((p.out_planes == 2 && p.planes == 2) || (p.out_planes == 3 && p.planes == 0))) return hipErrorInvalidValue;
     const WindowAttnParams& q = p2 ? *p2 : p;
@@ -558,7 +572,8 @@ hipError_t launch_window_attention2(const WindowAttnParams& p, const WindowAttnP
         hipLaunchKernelGGL(window_attention_bf16_kernel, grid, block, 0, s, p, q, n0);
     } else if (p.planes == 2) hipLaunchKernelGGL(window_attention_split_kernel<2>, grid, block, 0, s, p, q, n0);
     else if (p.planes == 1) hipLaunchKernelGGL(window_attention_split_kernel<1>, grid, block, 0, s, p, q, n0);
-    else hipLaunchKernelGGL(window_attention_f32_kernel, grid, block, 0, s, p, q, n0);
+    else if (ws == 7) hipLaunchKernelGGL(window_attention_f32_kernel<7>, grid, block, 0, s, p, q, n0);
+    else hipLaunchKernelGGL(window_attention_f32_kernel<12>, grid, block, 0, s, p, q, n0);
     return hipGetLastError();
 }
 hipError_t launch_window_attention(const WindowAttnParams& p, hipStream_t s) { return launch_window_attention2(p, nullptr, s); }

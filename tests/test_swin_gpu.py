@@ -1,0 +1,81 @@
+"""the stand-alone SwinTransformer (swin.rs:718-797, lib.rs:13) at every SwinConfig the reference defines
+(swin_t / swin_s: window 7, embed 96; swin_b: embed 128; swin_l) and at sizes that exercise PatchEmbed's pad-to-4 (swin.rs:696-702),
+PatchMerging's pad-to-even (swin.rs:496-503) and the window padding (swin.rs:359-366) — against the CPU oracle and the fp64 torch
+restatement.  Shapes of examples/test_swin.rs:60-71 (Swin-T, 1x3x256x256 -> [96,64,64] [192,32,32] [384,16,16] [768,8,8])."""
+import numpy as np
+import pytest
+import torch
+
+import torch_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(cfg, B, H, W, seed=3):
+    import candle_birefnet_amd as cb
+    from oracle import oracle as O
+    w = cb.synth_weights(cb.swin_weight_spec(cfg), seed=seed)
+    x = cb.synth_input(B, H, W)
+    m = cb.SwinTransformer.new(cfg, cb.VarBuilder.from_tensors(w))
+    outs = m.forward(x)
+    ocfg = O.make_cfg(depths=cfg.depths, embed_dim=cfg.embed_dim, num_heads=cfg.num_heads, window_size=cfg.window_size,
+                      patch_size=cfg.patch_size, in_channels=cfg.in_channels)
+    ref = O.swin_forward(ocfg, w, x)
+    m.close()
+    return w, x, outs, ref
+
+
+def _check(outs, ref, tol=2e-4):
+    assert len(outs) == 4
+    for a, b in zip(outs, ref):
+        assert a.shape == b.shape
+        err = float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())
+        assert err <= tol * max(1.0, float(np.abs(b).max())), f"max abs err {err:.3e}"
+
+
+def test_swin_t_256_shapes_and_oracle(gpu):
+    import candle_birefnet_amd as cb
+    cfg = cb.SwinConfig.swin_t()
+    w, x, outs, ref = _run(cfg, 1, 256, 256)
+    assert [o.shape for o in outs] == [(1, 96, 64, 64), (1, 192, 32, 32), (1, 384, 16, 16), (1, 768, 8, 8)]   # test_swin.rs:60-71
+    _check(outs, ref)
+    # the independent restatement in fp64 agrees too
+    t = R.swin_forward(torch.from_numpy(x).double(), w, cfg, "", torch.float64)
+    _check(outs, [a.numpy() for a in t])
+
+
+@pytest.mark.parametrize("name,depths,B,H,W", [
+    ("swin_t", [2, 2, 2, 2], 2, 250, 203),     # H, W % 4 != 0; odd maps at every PatchMerging; window 7 padding and shift 3
+    ("swin_t", [2, 2, 6, 2], 1, 61, 97),       # maps smaller than a window in the last stages
+    ("swin_s", [2, 2, 4, 2], 1, 224, 224),     # the ImageNet geometry: 56 = 8 windows of 7, no padding anywhere
+    ("swin_b", [2, 2, 2, 2], 1, 131, 90),      # embed 128, window 12, ragged
+    ("swin_l", [2, 2, 2, 2], 1, 130, 67),      # Swin-L widths through the stand-alone entry, odd sizes
+])
+def test_swin_configs_and_odd_sizes(gpu, name, depths, B, H, W):
+    import candle_birefnet_amd as cb
+    cfg = getattr(cb.SwinConfig, name)()
+    cfg.depths = list(depths)
+    w, x, outs, ref = _run(cfg, B, H, W)
+    hs, ws = -(-H // 4), -(-W // 4)
+    for i, o in enumerate(outs):
+        assert o.shape == (B, cfg.embed_dim << i, hs, ws)
+        hs, ws = (hs + 1) // 2, (ws + 1) // 2
+    _check(outs, ref)
+
+
+@pytest.mark.parametrize("H,W,shift", [(14, 14, 0), (14, 14, 3), (10, 17, 3), (7, 7, 0), (5, 9, 3)])
+def test_window_attention_window7(gpu, H, W, shift):
+    """the op-level entry with window 7 (49 tokens: the last 16-token tile is 15/16 dummy), padded and shifted maps"""
+    from candle_birefnet_amd import ops
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    C, heads = 96, 3
+    w = {"attn.qkv.weight": (rng.standard_normal((3 * C, C)) * C ** -0.5).astype(np.float32), "attn.qkv.bias": (rng.standard_normal(3 * C) * 0.2).astype(np.float32),
+         "attn.proj.weight": (rng.standard_normal((C, C)) * C ** -0.5).astype(np.float32), "attn.proj.bias": (rng.standard_normal(C) * 0.02).astype(np.float32),
+         "attn.relative_position_bias_table": (rng.standard_normal((169, heads)) * 0.5).astype(np.float32)}
+    x = rng.standard_normal((2, H, W, C)).astype(np.float32)
+    y = ops.window_attention(x, heads, shift, w["attn.qkv.weight"], w["attn.qkv.bias"], w["attn.proj.weight"], w["attn.proj.bias"],
+                             w["attn.relative_position_bias_table"], window_size=7)
+    ref = O.window_attention(x, heads, shift, w, window_size=7)
+    err = float(np.abs(np.asarray(y, np.float64) - ref).max())
+    assert err <= 3e-5 * max(1.0, float(np.abs(ref).max())), err
