@@ -1,0 +1,304 @@
+//! `BiRefNetConfig` / `BiRefNet` / `SqueezeModule` / `BiRefNetDecoder` of the reference (src/birefnet.rs:13-67, 70-94, 121-377,
+//! 380-476) over `brn_model_*` / `brn_forward*`.  One HBM-resident model handle is shared by the three pub fields the reference
+//! exposes (`backbone`, `squeeze_module`, `decoder`), which examples/bench_inference.rs:34,77,83 drive one by one.
+use std::sync::Arc;
+
+use candle_core::{Module, Result, Tensor};
+use candle_nn::VarBuilder;
+
+use crate::hip_ffi as ffi;
+use crate::swin::{stage_dims, swin_weight_spec, SwinConfig};
+
+/// BiRefNet configuration — the reference's struct, field for field (birefnet.rs:13-30)
+#[derive(Clone)]
+pub struct BiRefNetConfig {
+    pub size: (usize, usize),
+    pub backbone: String,
+    pub backbone_channels: Vec<usize>,
+    pub mul_scl_ipt: bool,
+    pub ms_supervision: bool,
+    pub dec_ipt: bool,
+    pub use_aspp_deformable: bool,
+    pub cxt: Vec<usize>,
+}
+
+impl Default for BiRefNetConfig {
+    /// birefnet.rs:32-46
+    fn default() -> Self {
+        Self {
+            size: (1024, 1024),
+            backbone: "swin_v1_l".to_string(),
+            backbone_channels: vec![192, 384, 768, 1536],
+            mul_scl_ipt: true,
+            ms_supervision: true,
+            dec_ipt: true,
+            use_aspp_deformable: true,
+            cxt: vec![192, 384, 768],
+        }
+    }
+}
+
+impl BiRefNetConfig {
+    /// birefnet.rs:50-53
+    pub fn lateral_channels(&self) -> Vec<usize> {
+        let m = if self.mul_scl_ipt { 2 } else { 1 };
+        self.backbone_channels.iter().map(|c| c * m).collect()
+    }
+    /// birefnet.rs:56-61
+    pub fn x4_channels(&self) -> usize {
+        let m = if self.mul_scl_ipt { 2 } else { 1 };
+        self.backbone_channels[3] * m + self.cxt.iter().map(|c| c * m).sum::<usize>()
+    }
+    /// birefnet.rs:64-66
+    pub fn swin_l() -> Self {
+        Self::default()
+    }
+
+    pub(crate) fn to_c(&self, deform_mode: i32) -> Result<ffi::BrnConfig> {
+        let mut c: ffi::BrnConfig = unsafe { std::mem::zeroed() };
+        unsafe { ffi::brn_config_default_swin_l(&mut c) };       // BiRefNet::new always builds swin_l (birefnet.rs:390-391)
+        if self.backbone_channels.len() != 4 || self.cxt.len() > 3 {
+            candle_core::bail!("backbone_channels must have 4 entries and cxt at most 3")
+        }
+        c.size_w = self.size.0 as i32;
+        c.size_h = self.size.1 as i32;
+        for (d, s) in c.backbone.iter_mut().zip(self.backbone.bytes().take(31)) {
+            *d = s as libc::c_char;
+        }
+        for i in 0..4 {
+            c.backbone_channels[i] = self.backbone_channels[i] as i32;
+        }
+        c.mul_scl_ipt = self.mul_scl_ipt as i32;
+        c.ms_supervision = self.ms_supervision as i32;
+        c.dec_ipt = self.dec_ipt as i32;
+        c.use_aspp_deformable = self.use_aspp_deformable as i32;
+        c.cxt = [0; 3];
+        for (i, v) in self.cxt.iter().enumerate() {
+            c.cxt[i] = *v as i32;
+        }
+        c.n_cxt = self.cxt.len() as i32;
+        c.deform_mode = deform_mode;
+        Ok(c)
+    }
+}
+
+// ---- the weight-name contract (birefnet.rs:170-273, decoder.rs:104-114, aspp.rs:39-45,247-290) ----
+type Spec = Vec<(String, Vec<usize>)>;
+
+fn conv(s: &mut Spec, p: &str, o: usize, cin: usize, k: usize, bias: bool) {
+    s.push((format!("{p}.weight"), vec![o, cin, k, k]));
+    if bias {
+        s.push((format!("{p}.bias"), vec![o]));
+    }
+}
+fn bn(s: &mut Spec, p: &str, c: usize) {
+    for leaf in ["weight", "bias", "running_mean", "running_var"] {
+        s.push((format!("{p}.{leaf}"), vec![c]));
+    }
+}
+/// BasicDecBlk::new + ASPPDeformable::new
+fn decblk(s: &mut Spec, p: &str, cin: usize, cout: usize) {
+    conv(s, &format!("{p}conv_in"), 64, cin, 3, true);
+    bn(s, &format!("{p}bn_in"), 64);
+    let ap = format!("{p}dec_att.");
+    for (module, k) in [("aspp1", 1usize), ("aspp_deforms.0", 1), ("aspp_deforms.1", 3), ("aspp_deforms.2", 7)] {
+        let cp = format!("{ap}{module}.atrous_conv.");
+        conv(s, &format!("{cp}offset_conv"), 2 * k * k, 64, k, true);
+        conv(s, &format!("{cp}modulator_conv"), k * k, 64, k, true);
+        conv(s, &format!("{cp}regular_conv"), 256, 64, k, false);
+        bn(s, &format!("{ap}{module}.bn"), 256);
+    }
+    conv(s, &format!("{ap}global_avg_pool.1"), 256, 64, 1, false);
+    bn(s, &format!("{ap}global_avg_pool.2"), 256);
+    conv(s, &format!("{ap}conv1"), 64, 1280, 1, false);
+    bn(s, &format!("{ap}bn1"), 64);
+    conv(s, &format!("{p}conv_out"), cout, 64, 3, true);
+    bn(s, &format!("{p}bn_out"), cout);
+}
+
+/// every tensor `BiRefNet::new` asks its VarBuilder for, including the loaded-but-unused heads (birefnet.rs:150-166, 229-243)
+pub fn weight_spec(config: &BiRefNetConfig) -> Spec {
+    let mut s = swin_weight_spec(&SwinConfig::swin_l(), "bb.");
+    let lat = config.lateral_channels();
+    decblk(&mut s, "squeeze_module.0.", config.x4_channels(), lat[3]);
+    let ipt_out = [48usize, 96, 192, 384, 384];
+    let ipt_in = [3usize, ipt_out[0], lat[0] / 2, lat[2] / 2, lat[3]];
+    for i in 0..5 {
+        let p = format!("decoder.ipt_blk{}.", i + 1);
+        conv(&mut s, &format!("{p}conv1"), 64, ipt_in[i], 3, true);
+        conv(&mut s, &format!("{p}conv_out"), ipt_out[i], 64, 3, true);
+    }
+    let dec_out = [lat[2], lat[1], lat[0], lat[0] / 2];
+    let dec_in = [lat[3] + ipt_out[4], dec_out[0] + ipt_out[3], dec_out[1] + ipt_out[2], dec_out[2] + ipt_out[1]];
+    for (i, n) in [4, 3, 2, 1].iter().enumerate() {
+        decblk(&mut s, &format!("decoder.decoder_block{n}."), dec_in[i], dec_out[i]);
+    }
+    for (n, c) in [(4, lat[2]), (3, lat[1]), (2, lat[0])] {
+        conv(&mut s, &format!("decoder.lateral_block{n}.conv"), c, c, 1, true);
+    }
+    for (i, n) in [4, 3, 2].iter().enumerate() {
+        let c = dec_out[i];
+        conv(&mut s, &format!("decoder.gdt_convs_{n}.0"), 16, c, 3, true);
+        bn(&mut s, &format!("decoder.gdt_convs_{n}.1"), 16);
+        conv(&mut s, &format!("decoder.gdt_convs_attn_{n}.0"), 1, 16, 1, true);
+        conv(&mut s, &format!("decoder.gdt_convs_pred_{n}.0"), 1, 16, 1, true);
+        conv(&mut s, &format!("decoder.conv_ms_spvn_{n}"), 1, c, 1, true);
+    }
+    conv(&mut s, "decoder.conv_out1.0", 1, dec_out[3] + ipt_out[0], 1, true);
+    s
+}
+
+// ---- the shared model handle ----
+struct Handle(*mut ffi::BrnModel);
+// forwards on one handle are serialised inside the library (mutex + stream event): safe to share
+unsafe impl Send for Handle {}
+unsafe impl Sync for Handle {}
+impl Drop for Handle {
+    fn drop(&mut self) {
+        unsafe { ffi::brn_model_destroy(self.0) }
+    }
+}
+
+/// `model.backbone` (a SwinTransformer in the reference): forward(x) -> [x1, x2, x3, x4]
+pub struct Backbone {
+    h: Arc<Handle>,
+}
+impl Backbone {
+    pub fn forward(&self, x: &Tensor) -> Result<Vec<Tensor>> {
+        let (b, _c, h, w) = x.dims4()?;
+        let xin = ffi::to_host(x)?;
+        let dims = stage_dims(h, w, 4);
+        let chans = [192usize, 384, 768, 1536];
+        let mut bufs: Vec<Vec<f32>> = (0..4).map(|i| vec![0f32; b * chans[i] * dims[i].0 * dims[i].1]).collect();
+        let ptrs: Vec<*mut f32> = bufs.iter_mut().map(|v| v.as_mut_ptr()).collect();
+        ffi::check(unsafe {
+            ffi::brn_model_backbone_forward(self.h.0, xin.as_ptr(), b as i32, h as i32, w as i32, ffi::BRN_MEM_HOST, ptrs.as_ptr(),
+                                            ffi::BRN_MEM_HOST, std::ptr::null_mut())
+        })?;
+        bufs.into_iter().enumerate().map(|(i, v)| Tensor::from_vec(v, (b, chans[i], dims[i].0, dims[i].1), x.device())).collect()
+    }
+}
+
+/// Squeeze module (birefnet.rs:70-94)
+pub struct SqueezeModule {
+    h: Arc<Handle>,
+    out_channels: usize,
+}
+impl Module for SqueezeModule {
+    fn forward(&self, x4: &Tensor) -> Result<Tensor> {
+        let (b, _c, h, w) = x4.dims4()?;
+        let xin = ffi::to_host(x4)?;
+        let mut out = vec![0f32; b * self.out_channels * h * w];
+        ffi::check(unsafe {
+            ffi::brn_model_squeeze_forward(self.h.0, xin.as_ptr(), b as i32, h as i32, w as i32, ffi::BRN_MEM_HOST, out.as_mut_ptr(),
+                                           ffi::BRN_MEM_HOST, std::ptr::null_mut())
+        })?;
+        Tensor::from_vec(out, (b, self.out_channels, h, w), x4.device())
+    }
+}
+
+/// BiRefNet decoder (birefnet.rs:121-377)
+pub struct BiRefNetDecoder {
+    h: Arc<Handle>,
+}
+impl BiRefNetDecoder {
+    /// birefnet.rs:278 — same signature
+    pub fn forward(&self, x: &Tensor, x1: &Tensor, x2: &Tensor, x3: &Tensor, x4: &Tensor) -> Result<Tensor> {
+        let (b, _c, h, w) = x.dims4()?;
+        let (xi, a1, a2, a3, a4) = (ffi::to_host(x)?, ffi::to_host(x1)?, ffi::to_host(x2)?, ffi::to_host(x3)?, ffi::to_host(x4)?);
+        let mut out = vec![0f32; b * h * w];
+        ffi::check(unsafe {
+            ffi::brn_model_decoder_forward(self.h.0, xi.as_ptr(), a1.as_ptr(), a2.as_ptr(), a3.as_ptr(), a4.as_ptr(), b as i32, h as i32, w as i32,
+                                           ffi::BRN_MEM_HOST, out.as_mut_ptr(), ffi::BRN_MEM_HOST, std::ptr::null_mut())
+        })?;
+        Tensor::from_vec(out, (b, 1, h, w), x.device())
+    }
+}
+
+/// BiRefNet model with Swin Transformer backbone (birefnet.rs:380-385): the same four pub fields
+pub struct BiRefNet {
+    pub config: BiRefNetConfig,
+    pub backbone: Backbone,
+    pub squeeze_module: SqueezeModule,
+    pub decoder: BiRefNetDecoder,
+    h: Arc<Handle>,
+}
+
+impl BiRefNet {
+    /// birefnet.rs:389 — same signature.  Compute mode and deform mode of the HIP backend come from the environment
+    /// (`BIREFNET_HIP_COMPUTE` = f32 | f32_split3 (default) | f32_split2 | bf16_operands | bf16; `BIREFNET_HIP_DEFORM` =
+    /// reference_cpu (default) | deformable) so that the reference's call sites compile unchanged.
+    pub fn new(config: BiRefNetConfig, vb: VarBuilder) -> Result<Self> {
+        let named = ffi::NamedTensors::from_varbuilder(&vb, &weight_spec(&config))?;
+        let c = config.to_c(deform_from_env())?;
+        let mut raw = std::ptr::null_mut();
+        ffi::check(unsafe {
+            ffi::brn_model_create(&c, named.views.as_ptr(), named.views.len(), 0, compute_from_env(), 1, config.size.1 as i32, config.size.0 as i32, &mut raw)
+        })?;
+        Ok(Self::wrap(config, raw))
+    }
+
+    /// `VarBuilder::from_mmaped_safetensors(&[path], DType::F32, &device)` + `BiRefNet::new` in one call (infer_image.rs:35-40):
+    /// the library memory-maps and parses the checkpoint itself, no tensor crosses the FFI
+    pub fn from_safetensors(config: BiRefNetConfig, path: &std::path::Path) -> Result<Self> {
+        let p = std::ffi::CString::new(path.to_string_lossy().as_bytes()).map_err(|e| candle_core::Error::Msg(e.to_string()))?;
+        let c = config.to_c(deform_from_env())?;
+        let mut raw = std::ptr::null_mut();
+        ffi::check(unsafe {
+            ffi::brn_model_create_from_safetensors(&c, p.as_ptr(), std::ptr::null(), 0, compute_from_env(), 1, config.size.1 as i32,
+                                                   config.size.0 as i32, &mut raw)
+        })?;
+        Ok(Self::wrap(config, raw))
+    }
+
+    fn wrap(config: BiRefNetConfig, raw: *mut ffi::BrnModel) -> Self {
+        let h = Arc::new(Handle(raw));
+        let out_channels = config.lateral_channels()[3];
+        Self { config, backbone: Backbone { h: h.clone() }, squeeze_module: SqueezeModule { h: h.clone(), out_channels }, decoder: BiRefNetDecoder { h: h.clone() }, h }
+    }
+
+    fn run(&self, x: &Tensor, sigmoid: bool) -> Result<Tensor> {
+        let (b, c, h, w) = x.dims4()?;
+        if c != 3 {
+            candle_core::bail!("expected [B,3,H,W], got {c} channels")
+        }
+        let xin = ffi::to_host(x)?;
+        let mut out = vec![0f32; b * h * w];
+        let f = if sigmoid { ffi::brn_forward } else { ffi::brn_forward_logits };
+        ffi::check(unsafe { f(self.h.0, xin.as_ptr(), b as i32, h as i32, w as i32, ffi::BRN_MEM_HOST, out.as_mut_ptr(), ffi::BRN_MEM_HOST, std::ptr::null_mut()) })?;
+        Tensor::from_vec(out, (b, 1, h, w), x.device())
+    }
+
+    /// birefnet.rs:412 — raw logits [B,1,H,W]
+    pub fn forward_logits(&self, x: &Tensor) -> Result<Tensor> {
+        self.run(x, false)
+    }
+
+    /// birefnet.rs:466 — sigmoid(forward_logits), fused in the library's final kernel
+    pub fn forward(&self, x: &Tensor) -> Result<Tensor> {
+        self.run(x, true)
+    }
+}
+
+/// birefnet.rs:472-476
+impl Module for BiRefNet {
+    fn forward(&self, xs: &Tensor) -> Result<Tensor> {
+        BiRefNet::forward(self, xs)
+    }
+}
+
+fn compute_from_env() -> i32 {
+    match std::env::var("BIREFNET_HIP_COMPUTE").as_deref() {
+        Ok("f32") => ffi::BRN_F32,
+        Ok("f32_split2") => ffi::BRN_F32_SPLIT2,
+        Ok("bf16_operands") => ffi::BRN_BF16_OPERANDS,
+        Ok("bf16") => ffi::BRN_BF16,
+        _ => ffi::BRN_F32_SPLIT3,
+    }
+}
+fn deform_from_env() -> i32 {
+    match std::env::var("BIREFNET_HIP_DEFORM").as_deref() {
+        Ok("deformable") => ffi::BRN_DEFORM_DEFORMABLE,
+        _ => ffi::BRN_DEFORM_REFERENCE_CPU,
+    }
+}

@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Consistency of rust_shim/ with include/birefnet_hip.h (the shim cannot be compiled in this image: no rustc):
+  * `#[repr(C)] BrnConfig` / `BrnNamedTensor` list the header's struct fields in the same order with matching C types;
+  * every entry point the header declares is declared exactly once in rust_shim/src/hip_ffi.rs, with the same number of
+    parameters, and hip_ffi.rs declares nothing else;
+  * the brn_dtype / brn_mem / brn_deform_mode constants agree;
+  * no todo!() / unimplemented!() anywhere in the shim.
+Exit code 0 = consistent.  Used by tests/test_rust_shim_cpu.py."""
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CT = {"int": "c_int", "float": "c_float", "char": "c_char", "double": "c_double"}
+
+
+def header_struct(text, name):
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), text, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = " ".join(decl.split())
+        if not decl:
+            continue
+        m = re.match(r"(const )?(\w+)\s*(\*?)\s*(.*)", decl)
+        const, ty, ptr, rest = m.groups()
+        for item in rest.split(","):
+            item = item.strip()
+            am = re.match(r"(\*?)(\w+)(?:\[(\d+)\])?$", item)
+            p2, fname, arr = am.groups()
+            fields.append((fname, ty, bool(ptr or p2), int(arr) if arr else 0))
+    return fields
+
+
+def rust_struct(text, name):
+    body = re.search(r"pub struct %s \{(.*?)\n\}" % name, text, re.S).group(1)
+    fields = []
+    for m in re.finditer(r"pub (\w+): ([^,\n]+),", body):
+        fields.append((m.group(1), m.group(2).strip()))
+    return fields
+
+
+def header_functions(text):
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\n(?:brn_status|void|int|const char\*)\s+(brn_\w+)\s*\((.*?)\);", text, re.S):
+        args = " ".join(m.group(2).split())
+        n = 0 if args in ("void", "") else len(args.split(","))
+        out[m.group(1)] = n
+    return out
+
+
+def rust_functions(text):
+    ext = re.search(r'extern "C" \{(.*?)\n\}', text, re.S).group(1)
+    out = {}
+    for m in re.finditer(r"pub fn (brn_\w+)\s*\((.*?)\)\s*(?:->\s*[^;]+)?;", ext, re.S):
+        args = " ".join(m.group(2).split())
+        out.setdefault(m.group(1), []).append(0 if not args else len(args.split(",")))
+    return out
+
+
+def main():
+    h = open(os.path.join(ROOT, "include", "birefnet_hip.h")).read()
+    r = open(os.path.join(ROOT, "rust_shim", "src", "hip_ffi.rs")).read()
+    errs = []
+    for cname, rname in (("brn_config", "BrnConfig"), ("brn_named_tensor", "BrnNamedTensor")):
+        hf, rf = header_struct(h, cname), rust_struct(r, rname)
+        if [f[0] for f in hf] != [f[0] for f in rf]:
+            errs.append(f"{rname}: field order {[f[0] for f in rf]} != header {[f[0] for f in hf]}")
+            continue
+        for (fname, ty, ptr, arr), (_, rty) in zip(hf, rf):
+            want = CT.get(ty, {"int64_t": "i64"}.get(ty, ty))
+            if ptr:
+                ok = rty.startswith("*const ") and rty.endswith(want)
+            elif arr:
+                ok = rty == f"[{want}; {arr}]"
+            else:
+                ok = rty == want
+            if not ok:
+                errs.append(f"{rname}.{fname}: rust type {rty} does not match C {ty}{'*' if ptr else ''}{'[%d]' % arr if arr else ''}")
+    hf, rf = header_functions(h), rust_functions(r)
+    for name, n in hf.items():
+        if name not in rf:
+            errs.append(f"{name}: declared in the header, missing from hip_ffi.rs")
+        elif len(rf[name]) != 1:
+            errs.append(f"{name}: declared {len(rf[name])} times in hip_ffi.rs")
+        elif rf[name][0] != n:
+            errs.append(f"{name}: {rf[name][0]} parameters in hip_ffi.rs, {n} in the header")
+    for name in rf:
+        if name not in hf:
+            errs.append(f"{name}: in hip_ffi.rs but not in the header")
+    for const, enum_pat in (("BRN_F32", 0), ("BRN_F32_SPLIT3", 1), ("BRN_F32_SPLIT2", 2), ("BRN_BF16_OPERANDS", 3), ("BRN_BF16", 4),
+                            ("BRN_MEM_HOST", 0), ("BRN_MEM_DEVICE", 1), ("BRN_DEFORM_REFERENCE_CPU", 0), ("BRN_DEFORM_DEFORMABLE", 1)):
+        hm = re.search(r"\b%s = (\d+)" % const, h)
+        rm = re.search(r"pub const %s: c_int = (\d+);" % const, r)
+        if not hm or not rm or int(hm.group(1)) != enum_pat or int(rm.group(1)) != enum_pat:
+            errs.append(f"constant {const} disagrees (header {hm and hm.group(1)}, rust {rm and rm.group(1)})")
+    for fn in os.listdir(os.path.join(ROOT, "rust_shim", "src")):
+        t = open(os.path.join(ROOT, "rust_shim", "src", fn)).read()
+        for bad in ("todo!(", "unimplemented!(", "unreachable!("):
+            if bad in t:
+                errs.append(f"rust_shim/src/{fn} contains {bad})")
+    for e in errs:
+        print("MISMATCH:", e)
+    print(f"{len(hf)} header entry points, {len(rf)} in hip_ffi.rs, {len(errs)} problem(s)")
+    return 1 if errs else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
