@@ -44,6 +44,19 @@ __device__ __forceinline__ float gelu_erf_b(float x) {   // same fit as gemm_f32
     return 0.5f * x * one_plus_erf;
 }
 
+// gelu_erf for a result that is rounded to bf16 right away (flavour 0): erfc by Abramowitz-Stegun 7.1.25 (3 terms), |gelu error|
+// < 2.6e-5 absolute and < 0.23 % relative for |gelu| >= 1e-2 — under half a bf16 ulp (0.39 %) — at half the VALU work of the
+// degree-7 fit, which the fp32 outputs keep.  (fc1's epilogue is VALU time the persistent workgroup cannot hide behind MFMAs.)
+__device__ __forceinline__ float gelu_erf_bf16out(float x) {
+    const float s = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.47047f, s, 1.0f));
+    float q = fmaf(0.7478556f, t, -0.0958798f);
+    q = fmaf(q, t, 0.3480242f);
+    q = q * t * __expf(-s * s);
+    const float one_plus_erf = x < 0.f ? q : 2.0f - q;
+    return 0.5f * x * one_plus_erf;
+}
+
 __device__ __forceinline__ void bf16_tile_coords(int tile, int tilesM, int tilesN, int& tm, int& tn) {
     constexpr int GN = 8;            // N walked in groups of 8 tile columns, M fastest-but-one inside a group (L2 reuse of the W panels)
     const int per_group = tilesM * GN;
@@ -426,7 +439,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
                             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                         } else if (act == ACT_GELU_ERF) {
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = gelu_erf_b(v[e]);
+                            for (int e = 0; e < 8; ++e) v[e] = EPI == 0 ? gelu_erf_bf16out(v[e]) : gelu_erf_b(v[e]);
                         }
                         if (EPI == 0) {
                             if (p.R) {                           // bf16 residual (the decoder's lateral adds, in place)
