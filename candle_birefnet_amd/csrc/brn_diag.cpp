@@ -130,15 +130,17 @@ brn_status brn_gemm_microbench(int M, int N, int K, int tile_cfg, int splitk, in
             set_build_planes(BUILD_BF16);
             GemmW gw = make_linear(own, hw.data(), nullptr, N, K);
             set_build_planes(0);
-            std::vector<float> hc((size_t)M * N / 2 + 64, 0.f);
+            const bool epi1 = getenv("BRN_GEMM_EPI1") != nullptr;      // fp32 C + fp32 residual in place (proj / fc2) instead of bf16 C
+            std::vector<float> hc(epi1 ? (size_t)M * N : (size_t)M * N / 2 + 64, 0.f);
             float* dC = own.upload(hc);
-            GemmPlan pl = plan_gemm_bf16(M, N, K);
+            GemmPlan pl = plan_gemm_bf16(M, N, K, epi1);
             if (tile_cfg >= 0) { pl.cfg = tile_cfg; pl.splitk = splitk > 1 ? splitk : 1; pl.ws_floats = pl.splitk > 1 ? (size_t)pl.splitk * M * N : 0; }
             float* ws = nullptr;
             if (pl.ws_floats) { std::vector<float> z(pl.ws_floats, 0.f); ws = own.upload(z); }
             GemmParams p{};
             p.A = (const float*)dAb; p.C = dC; p.M = M; p.N = N; p.K = K; p.mode = GEMM_DENSE; p.lda = K; p.ldc = N; p.bbias_rows = 1;
             p.Wp = gw.wb; p.wp_rows = gw.wb_rows; p.wp_ld = gw.wb_ld; p.planes = 1;
+            if (epi1) { p.c_f32 = 1; p.R = dC; p.r_f32 = 1; p.ldr = N; }
             if (const char* ab = getenv("BRN_GEMM_ABLATE")) p.abl = atoi(ab);
             std::vector<float> hb((size_t)N, 0.1f);
             if (const char* ac = getenv("BRN_GEMM_ACT")) { p.act = atoi(ac); p.bias = own.upload(hb); }

@@ -18,12 +18,20 @@
 //     ADDRESS, never on the data.
 #include "../brn_kernels.h"
 #include "split_planes.h"
+#include <type_traits>
 
 namespace brn {
 
 typedef float f32x16_b __attribute__((ext_vector_type(16)));
 typedef float f32x4_b __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4_b __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_b __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {      // v_cvt_pk_bf16_f32 (round to nearest even): lo in bits 0-15
+    typedef __bf16 bf16x2_b __attribute__((ext_vector_type(2)));
+    const bf16x2_b t = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, t);
+}
 
 __device__ __attribute__((aligned(16))) unsigned g_zero_page[64];   // 256 zero bytes (code-object global: zero-initialised)
 
@@ -65,6 +73,24 @@ __device__ __forceinline__ void bf16_tile_coords(int tile, int tilesM, int tiles
     tm = r / gw;
     tn = g * GN + (r - tm * gw);
 }
+
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
+#ifndef BRN_BF16_SCHED
+#define BRN_BF16_SCHED 1
+#endif
+constexpr bool SCHED = BRN_BF16_SCHED != 0;
+#ifndef BRN_BF16_MFMA16
+#define BRN_BF16_MFMA16 1
+#endif
+#ifndef BRN_BF16_BSINGLE
+#define BRN_BF16_BSINGLE 1
+#endif
+#ifndef BRN_BF16_CFG2_M16          // the 256 x 256 tile keeps 32x32x16 with both fragment sets double-buffered: with 16x16x32 it has no
+#define BRN_BF16_CFG2_M16 0        // registers left (spills, rematerialised addresses) and measured 7 % slower; the smaller tiles gain 5-13 %
+#endif
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -150,10 +176,13 @@ __device__ __forceinline__ void store_row8(const GemmParams& p, int m, int n, fl
 // item's C rows are stored, and those stores are not waited for before the next K loop starts (counted vmcnt: loads, stores
 // and LDS-DMA retire in issue order).  Measured before (one workgroup per tile, tools/gemm_bf16_ablate.py, 40960 x 2304 x 768):
 // 49 us of 264 were workgroup launch + prologue, 68 the epilogue, 64 exposed load latency, 83 the MFMA loop itself.
-template <int BM, int BN, int WM, int WN, int NSTAGE, int MODE, int BBK, int EPI>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int MODE, int BBK, int EPI, bool M16 = BRN_BF16_MFMA16 != 0, bool BSINGLE = BRN_BF16_BSINGLE != 0>
 __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams p) {
     constexpr int NW = WM * WN;
-    constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+    constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;   // TM x TN: 32 x 32 blocks of a wave tile (epilogue rounds)
+    // MFMA shape: 16x16x32 by default — the same cycles per flop as 32x32x16, but the chip holds a higher clock under it
+    // (MI355X_MICROARCH.md, DVFS item 7: x 1.12-1.14 in LDS-fed bf16 loops on random data); fragments are FR rows x (BBK / KSUB) k
+    constexpr int FR = M16 ? 16 : 32, FM = WTM / FR, FN = WTN / FR;
     constexpr int ROWB = BBK * 2;                               // bytes per tile row
     constexpr int RPB = 256 / ROWB, CPR = BBK / 8;              // tile rows per bank row, 16-byte chunks per tile row
     constexpr int SWZ_MASK = BBK == 64 ? 15 : 3;
@@ -165,24 +194,23 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
     static_assert(NSTAGE >= 2 && NSTAGE <= 4, "ring depth");
     constexpr int LPS = LA + LB;                                // vmcnt units per stage and wave
     constexpr int A_BYTES = BM * ROWB, STAGE_BYTES = (BM + BN) * ROWB;
-    // epilogue patches (one per wave, PR rows x EWN floats, unpadded, 16-byte chunks XOR-ed with the row parity) live in the LAST ring
-    // slot; a wave's WTM x WTN accumulators go through it in blocks of PR rows x EWN columns
-    constexpr int EWN = (WTN % 64 == 0) ? 64 : 32;
-    constexpr int NJB = WTN / EWN, JPB = EWN / 32;              // column blocks per wave tile, 32-wide MFMA tiles per column block
-    constexpr int PR = (NW * 32 * EWN * 4 <= STAGE_BYTES) ? 32 : (NW * 16 * EWN * 4 <= STAGE_BYTES) ? 16 : 8;
-    static_assert(NW * PR * EWN * 4 <= STAGE_BYTES, "epilogue patches must fit one ring slot");
-    constexpr int NB = 32 / PR;                                 // patch blocks per 32-row accumulator block
-    constexpr int LPR = EWN / 8, RPP = 64 / LPR;                // lanes per row (8 outputs each), rows per pass
-    constexpr int PASSES = PR / RPP;
-    static_assert(PASSES >= 1, "patch smaller than one pass");
-    constexpr int STORES = TM * NJB * NB * PASSES * (EPI == 1 ? 2 : 1);   // store instructions per wave and FULL tile (flavours 0 / 1)
+    // Epilogue: the product is formed TRANSPOSED (the W fragment is the MFMA's first operand), so per MFMA block a lane holds ONE row
+    // m of C and 4 consecutive columns per 4 registers (16x16: columns 4 (lane >> 4) + {0..3}; 32x32: 8g + 4 (lane >> 5) + {0..3} in
+    // registers 4g .. 4g+3) — 16-byte row pieces for ds_write_b128.  One patch per wave (32 rows x EWN fp32, 16-byte chunks XOR-ed
+    // with the row: conflict-free both ways) in the LAST ring slot; a wave tile goes through it in TM x NJB rounds.
+    constexpr int EWN = (WTN % 64 == 0 && NW * 32 * 64 * 4 <= STAGE_BYTES) ? 64 : 32;
+    constexpr int NJB = WTN / EWN;                              // column blocks per wave tile
+    static_assert(NW * 32 * EWN * 4 <= STAGE_BYTES, "epilogue patches must fit one ring slot");
+    constexpr int LPR = EWN / 8, RPP = 64 / LPR;                // read-back: lanes per row (8 outputs each), rows per pass
+    constexpr int PASSES = 32 / RPP;
+    constexpr int STORES = TM * NJB * PASSES * (EPI == 1 ? 2 : 1);   // store instructions per wave and FULL tile (flavours 0 / 1)
     __shared__ __attribute__((aligned(1024))) char smem[NSTAGE * STAGE_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 #ifdef BRN_DIAG_BUILD
-    const int abl = p.abl;       // 1: no A loads, 2: no W loads, 4: no fragment reads / MFMA, 8: no epilogue
+    const int abl = p.abl;       // 1: no A loads, 2: no W loads, 4: no fragment reads / MFMA, 8: no epilogue, 16: epilogue without its (bf16) stores
 #else
     constexpr int abl = 0;
 #endif
@@ -210,13 +238,11 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
     const __bf16* Ab = reinterpret_cast<const __bf16*>(p.A);
     const __bf16* Wb = reinterpret_cast<const __bf16*>(p.Wp);
 
-    // fragment addressing: lane reads row (lane & 31) of a 32-row block, logical chunk 2 s + (lane >> 5) at k16 step s
-    constexpr int KS16 = BBK / 16;
-    const int frow = lane & 31, fh = lane >> 5;
-    const int fswz = (frow / RPB) & SWZ_MASK;                    // same for every 32-row block (blocks are 32 / RPB bank rows apart)
-    int foff[KS16];
-#pragma unroll
-    for (int s = 0; s < KS16; ++s) foff[s] = (frow / RPB) * 256 + ((((frow % RPB) * CPR + (2 * s + fh)) ^ fswz) << 4);
+    // fragment addressing: 32x32x16: lane reads row (lane & 31) of a 32-row block, logical chunk 2 s + (lane >> 5) at k16 step s;
+    // 16x16x32: row (lane & 15) of a 16-row block, chunk 4 s + (lane >> 4) at k32 step s.  With 128-byte tile rows a 16-row block is 8
+    // bank rows, so odd blocks see the XOR key (p & 15) with bit 3 flipped: their offsets are foff ^ 128.
+    constexpr int KSUB = BBK / (M16 ? 32 : 16);
+    constexpr int ODD_FLIP = (M16 && BBK == 64) ? 128 : 0;      // (BBK 32: 4 rows per bank row, key p & 3: a 16-row block is 4 bank rows, no flip)
     const int a_base = wm * WTM * ROWB, b_base = A_BYTES + wn * WTN * ROWB;
 
     // ---- state of the work item whose K steps are being staged ----
@@ -260,38 +286,40 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
         // W rows n0 + lrow + RPI NW j of the padded [rows][wp_ld] bf16 matrix (rows and K zero-padded to the tile: always in bounds)
         w_off0 = (long)(n0 + lrow) * p.wp_ld + kch;
     };
-    auto stage = [&](int t) {                                   // issue the loads of K step t (local index) into ring slot t % NSTAGE
+    // piece j of K step t (local index) into ring slot t % NSTAGE: j < LA = A rows, else W rows; stage_advance() after the last piece
+    auto stage_piece = [&](int t, int j) {
         char* sbase = smem + (t % NSTAGE) * STAGE_BYTES + wave * 1024;
         const int kbase = (kt0 + t) * BBK;
-        if (MODE == GEMM_DENSE) {
-            const bool kin = kbase + kch < p.K;                  // K tail (K % 64 == 32): the upper chunks read zeros
-#pragma unroll
-            for (int j = 0; j < LA; ++j) {
+        if (j < LA) {
+            if (MODE == GEMM_DENSE) {
+                const bool kin = kbase + kch < p.K;              // K tail (K % 64 == 32): the upper chunks read zeros
                 const char* src = (a_ok[j] && kin) ? reinterpret_cast<const char*>(Ab + a_off[j] + kbase) : zero;
                 if (!(abl & 1)) glds16(src, sbase + j * (NW * 1024));
-            }
-        } else {
-            const bool kin = c_ky < p.kh;                        // beyond the last tap: K tail
-            const int dy = c_ky * p.dil, dx = c_kx * p.dil;
-#pragma unroll
-            for (int j = 0; j < LA; ++j) {
-                const int iy = a_iy[j] + dy, ix = a_ix[j] + dx;
+            } else {
+                const bool kin = c_ky < p.kh;                    // beyond the last tap: K tail
+                const int iy = a_iy[j] + c_ky * p.dil, ix = a_ix[j] + c_kx * p.dil;
                 const bool ok = a_ok[j] && kin && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
                 const char* src = ok ? reinterpret_cast<const char*>(Ab + a_off[j] + ((long)iy * p.Win + ix) * p.lda + c_ci) : zero;
                 if (!(abl & 1)) glds16(src, sbase + j * (NW * 1024));
             }
+        } else {
+            const int jw = j - LA;
+            if (!(abl & 2)) glds16(Wb + w_off0 + (long)(RPI * NW * jw) * p.wp_ld + kbase, sbase + A_BYTES + jw * (NW * 1024));
+        }
+    };
+    auto stage_advance = [&]() {
+        if (MODE == GEMM_CONV_NHWC) {
             c_ci += BBK;
             if (c_ci >= p.Cin) { c_ci -= p.Cin; if (++c_kx == p.kw) { c_kx = 0; ++c_ky; } }
         }
+    };
+    auto stage = [&](int t) {                                   // all pieces of K step t at once (prologue of a work item)
 #pragma unroll
-        for (int j = 0; j < LB; ++j)
-            if (!(abl & 2)) glds16(Wb + w_off0 + (long)(RPI * NW * j) * p.wp_ld + kbase, sbase + A_BYTES + j * (NW * 1024));
+        for (int j = 0; j < LPS; ++j) stage_piece(t, j);
+        stage_advance();
     };
 
     // ---- epilogue constants ----
-    float* patch = reinterpret_cast<float*>(smem + (NSTAGE - 1) * STAGE_BYTES) + wave * (PR * EWN);
-    const int col = lane & 31, rhalf = (lane >> 5) * 4;           // C/D map: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    const int er = lane / LPR, ec = (lane % LPR) * 8;             // read-back map: row er of a pass, columns ec .. ec + 7
     const bool has_scale = p.scale != nullptr;
     const int act = p.act;
 
@@ -304,15 +332,21 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
     }
     bool counted = false;        // the previous item's epilogue issued exactly STORES stores per wave after this item's first loads
     while (have) {
-        f32x16_b acc[TM][TN];
+        typename std::conditional<M16, f32x4_b, f32x16_b>::type acc[FM][FN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < FN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int r = 0; r < (M16 ? 4 : 16); ++r) acc[i][j][r] = 0.f;
 
-        for (int t = 0; t < nt; ++t) {
+        // One K step.  STAGE_NEXT: the loads of step t + NSTAGE - 1 are part of the step's straight-line block, and the block's
+        // issue order is pinned (sched_group_barrier): left to itself the scheduler issued all LPS LDS-DMA pieces right after the
+        // barrier (60-180 issue cycles each, every wave of the CU at once: the matrix pipe idles meanwhile) and re-used ONE
+        // fragment register set, reading step s+1's fragments only after step s's last MFMA.  Pinned order: the fragments of
+        // k16 step s+1 (second register set) and a share of the LDS-DMA pieces are issued one at a time BETWEEN the MFMAs of step s.
+        auto kstep = [&](int t, auto stage_next) {
+            constexpr bool STAGE_NEXT = decltype(stage_next)::value;
             // K step t has landed once at most `after` younger steps (and, at t = 0, the previous item's stores) are outstanding
             const int after = min(nt - 1, t + NSTAGE - 2) - t;
             if (t == 0 && counted && after == NSTAGE - 2) wait_vmcnt<(NSTAGE - 2) * LPS + STORES>();
@@ -320,29 +354,75 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
             else if (NSTAGE >= 3 && after >= 1) wait_vmcnt<LPS>();
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();                        // every wave's part of step t is in LDS; slot (t-1) % NSTAGE is free
-            if (t + NSTAGE - 1 < nt) stage(t + NSTAGE - 1);
-            if (abl & 4) continue;
+            if (abl & 4) { if (STAGE_NEXT) stage(t + NSTAGE - 1); return; }
             const char* sb = smem + (t % NSTAGE) * STAGE_BYTES;
-            // fragments of k16 step s+1 are read while the MFMAs of step s run (two register sets)
-            bf16x8 af[2][TM], bf[2][TN];
+            // the fragment offsets are recomputed per K step from an opaque copy of the lane id (a dozen VALU beside 64 MFMAs): kept in
+            // registers across the persistent loop they were the values the allocator chose to spill, and reloaded here every step
+            int flane = lane;
+            asm volatile("" : "+v"(flane));
+            const int frow = flane & (FR - 1), fh = flane / FR;
+            const int fswz = (frow / RPB) & SWZ_MASK;
+            int foff[KSUB];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(sb + a_base + i * (32 * ROWB) + foff[0]);
+            for (int s = 0; s < KSUB; ++s) foff[s] = (frow / RPB) * 256 + ((((frow % RPB) * CPR + ((M16 ? 4 : 2) * s + fh)) ^ fswz) << 4);
+            constexpr int NF = FM + FN, NM = FM * FN;              // fragment reads and MFMAs per sub-step (k16 / k32)
+            constexpr int DMA_STEPS = KSUB > 1 ? KSUB - 1 : 1;     // the pieces go out during the first KSUB-1 k16 steps
+            constexpr bool PIN = SCHED && NM >= (LPS + DMA_STEPS - 1) / DMA_STEPS && (BSINGLE || NM >= NF);   // (tiny wave tiles: left to the scheduler)
+            // MFMA order inside a sub-step: W block j outer, A block i inner (m = j FM + i).  The W fragments are single-buffered: the
+            // fragment of block j for sub-step S + 1 is read right after the last MFMA that used it in sub-step S (m = j FM + FM - 1); the
+            // A fragments (all live to the end of the sub-step) are double-buffered and read after the first FM MFMAs.
+            bf16x8 af[2][FM], bf[2][FN];
+            auto read_a = [&](int s, int f) {
+                af[s & 1][f] = *reinterpret_cast<const bf16x8*>(sb + a_base + f * (FR * ROWB) + (foff[s % KSUB] ^ ((f & 1) ? ODD_FLIP : 0)));
+            };
+            auto read_b = [&](int s, int f) {
+                bf[s & 1][f] = *reinterpret_cast<const bf16x8*>(sb + b_base + f * (FR * ROWB) + (foff[s % KSUB] ^ ((f & 1) ? ODD_FLIP : 0)));
+            };
+            if (!PIN && STAGE_NEXT) stage(t + NSTAGE - 1);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const bf16x8*>(sb + b_base + j * (32 * ROWB) + foff[0]);
+            for (int f = 0; f < FM; ++f) read_a(0, f);
 #pragma unroll
-            for (int s = 0; s < KS16; ++s) {
-                if (s + 1 < KS16) {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) af[(s + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(sb + a_base + i * (32 * ROWB) + foff[(s + 1) % KS16]);
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) bf[(s + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(sb + b_base + j * (32 * ROWB) + foff[(s + 1) % KS16]);
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][i], bf[s & 1][j], acc[i][j], 0, 0, 0);
+            for (int f = 0; f < FN; ++f) read_b(0, f);
+            // Source order = issue order of the LDS traffic (the compiler keeps ds_read / LDS-DMA order: it cannot prove them
+            // disjoint); the MFMAs are pinned between them by the sched_group_barrier sequence below.
+            static_for<0, KSUB>([&](auto sc) {
+                constexpr int S = decltype(sc)::value;
+                constexpr int d0 = S < DMA_STEPS ? (LPS * S) / DMA_STEPS : LPS, d1 = S < DMA_STEPS ? (LPS * (S + 1)) / DMA_STEPS : LPS;
+                static_for<0, NM>([&](auto mc) {
+                    constexpr int Mi = decltype(mc)::value;
+                    if (S + 1 < KSUB && Mi < FM) read_a(S + 1, Mi);
+                    if (BSINGLE && S + 1 < KSUB && Mi % FM == FM - 1) read_b(S + 1, Mi / FM);
+                    if (!BSINGLE && S + 1 < KSUB && Mi >= FM && Mi < NF) read_b(S + 1, Mi - FM);
+                    if (PIN && STAGE_NEXT && Mi < d1 - d0) stage_piece(t + NSTAGE - 1, d0 + Mi);
+                });
+                static_for<0, NM>([&](auto mc) {                  // transposed product: W fragment first
+                    constexpr int Mi = decltype(mc)::value;
+                    constexpr int i = BSINGLE ? Mi % FM : Mi / FN, j = BSINGLE ? Mi / FM : Mi % FN;
+                    if constexpr (M16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[S & 1][j], af[S & 1][i], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[S & 1][j], af[S & 1][i], acc[i][j], 0, 0, 0);
+                });
+            });
+            if (PIN && STAGE_NEXT) stage_advance();
+            if (PIN) {
+                __builtin_amdgcn_sched_group_barrier(0x100, NF, 0);  // sub-step 0's fragments
+                static_for<0, KSUB>([&](auto sc) {
+                    constexpr int S = decltype(sc)::value;
+                    constexpr int d0 = S < DMA_STEPS ? (LPS * S) / DMA_STEPS : LPS, d1 = S < DMA_STEPS ? (LPS * (S + 1)) / DMA_STEPS : LPS;
+                    static_for<0, NM>([&](auto mc) {
+                        constexpr int Mi = decltype(mc)::value;
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (S + 1 < KSUB && Mi < FM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        if (BSINGLE && S + 1 < KSUB && Mi % FM == FM - 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        if (!BSINGLE && S + 1 < KSUB && Mi >= FM && Mi < NF) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        if (STAGE_NEXT && Mi < d1 - d0) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                    });
+                });
             }
+        };
+        {
+            int t = 0;
+            for (; t + NSTAGE - 1 < nt; ++t) kstep(t, std::true_type{});
+            for (; t < nt; ++t) kstep(t, std::false_type{});
         }
 
         // ---- hand over: the finished item keeps (e_m0, e_n0, e_slice); the staging state moves on to the next item ----
@@ -358,113 +438,169 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
         }
         if (abl & 8) { if (acc[0][0][0] == 123.456f) p.C[0] = 1.f; counted = false; continue; }
 
-        // ---- epilogue: PR x WTN row blocks through the wave's LDS patch (last ring slot), whole row segments to HBM ----
-        const bool split = EPI == 2 && p.splitk > 1;
-        float* part = split ? p.part + (long)e_slice * p.M * p.N : nullptr;
-        const long rowbase = (long)(e_m0 + wm * WTM);
+        {
+            // ---- epilogue, flavours 0 / 1.  The product was formed transposed: per 32 x 32 block a lane holds row (lane & 31), columns
+            // 8g + 4h + {0..3} in registers 4g .. 4g+3 (h = lane >> 5) = whole 16-byte pieces of a row.  A (row block i, column block jb)
+            // round puts the wave's 32 x EWN fp32 block into its LDS patch with ds_write_b128 (16-byte chunks XOR-ed with the row:
+            // conflict-free both ways) and reads it back as row segments of 8 columns per lane: a lane's columns are then the same for
+            // the whole column block (bias / BN constants in registers), rows are stored as whole 128/256-byte segments.  The code is
+            // specialised (activation, BN, full tile) so that a pass is ~20 instructions: the first version of this epilogue tested
+            // every flag per pass and recomputed 64-bit addresses (~1900 instructions per wave and tile = 7 us on a 256 x 256 tile). ----
+            constexpr int CM = EWN / 4 - 1;                            // chunk mask of a patch row
+            // the lane id goes through an opaque asm once per tile: everything the epilogue derives from it (patch addresses, row /
+            // column offsets) is recomputed here instead of being hoisted out of the persistent loop into registers that would
+            // then be live across the K loop (which has none to spare: the hoisted version spilled)
+            int elane = lane;
+            asm volatile("" : "+v"(elane));
+            const int wrow = elane & (FR - 1), wt = (elane / FR) ^ (wrow & CM);   // write map: patch row (+ 16 ii), chunk key
+            const int er = elane / LPR, ec = (elane % LPR) * 8;       // read-back map: row er of a pass, columns ec .. ec + 7
+            char* wpatch = smem + (NSTAGE - 1) * STAGE_BYTES + wave * (32 * EWN * 4);
+            char* wbase = wpatch + wrow * (EWN * 4);
+            const int esz = EPI == 0 ? 2 : 4;
+            const long row0 = e_m0 + wm * WTM;                         // first row of the wave tile
+            const bool full = e_m0 + BM <= p.M && e_n0 + BN <= p.N;
+            auto run = [&](auto act_c, auto scale_c, auto full_c) {
+                constexpr int ACT = decltype(act_c)::value;
+                constexpr bool SCALE = decltype(scale_c)::value, FULL = decltype(full_c)::value;
+                // rounds r = jb * TM + i; flavour 1 keeps ONE round of fp32 residual rows in registers: the rows of pass ps of round r + 1
+                // are requested as soon as pass ps of round r has used its registers (the K loop has no registers to spare for more)
+                f32x4_b rres[PASSES][2];
+                auto load_res = [&](int r, int ps) {
+                    const int jb = r / TM, i = r % TM;
+                    const int n = e_n0 + wn * WTN + jb * EWN + ec;
+                    const long mb = row0 + i * 32;
+                    const bool ok = FULL || (mb + ps * RPP + er < p.M && n < p.N);
+                    const char* rp = reinterpret_cast<const char*>(p.R) + (mb * p.ldr + p.r_coff + (n - ec)) * 4 + (long)(ps * RPP) * p.ldr * 4 +
+                                     (unsigned)(er * p.ldr + ec) * 4;
+                    if (!ok) rp = reinterpret_cast<const char*>(g_zero_page);
+                    rres[ps][0] = *reinterpret_cast<const f32x4_b*>(rp);
+                    rres[ps][1] = *reinterpret_cast<const f32x4_b*>(rp + 16);
+                };
+                const bool has_res1 = EPI == 1 && p.R != nullptr;
+                if (has_res1) {
 #pragma unroll
-        for (int jb = 0; jb < NJB; ++jb) {
-            const int n = e_n0 + wn * WTN + jb * EWN + ec;
-            float bias[8], sc[8], sh[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                bias[e] = 0.f; sc[e] = 1.f; sh[e] = 0.f;
-                if (!split && n + e < p.N) {
-                    if (p.bias) bias[e] = p.bias[n + e];
-                    if (has_scale) { sc[e] = p.scale[n + e]; sh[e] = p.shift[n + e]; }
+                    for (int ps = 0; ps < PASSES; ++ps) load_res(0, ps);
                 }
-            }
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
+                for (int jb = 0; jb < NJB; ++jb) {
+                    const int n = e_n0 + wn * WTN + jb * EWN + ec;   // this lane's 8 columns after the read-back
+                    const bool nin = FULL || n < p.N;
+                    const int nl = nin ? n : 0;
+                    f32x4_b bias0 = zero4b(), bias1 = zero4b(), sc0, sc1, sh0, sh1;
+                    if (EPI != 2 && p.bias) { bias0 = *reinterpret_cast<const f32x4_b*>(p.bias + nl); bias1 = *reinterpret_cast<const f32x4_b*>(p.bias + nl + 4); }
+                    if (EPI != 2 && SCALE) {
+                        sc0 = *reinterpret_cast<const f32x4_b*>(p.scale + nl); sc1 = *reinterpret_cast<const f32x4_b*>(p.scale + nl + 4);
+                        sh0 = *reinterpret_cast<const f32x4_b*>(p.shift + nl); sh1 = *reinterpret_cast<const f32x4_b*>(p.shift + nl + 4);
+                    }
+                    // per-lane byte offsets inside a pass (32-bit) on top of uniform row pointers
+                    const unsigned coff = (unsigned)(er * p.ldc + ec) * esz, roff = (unsigned)(er * p.ldr + ec) * 2;
 #pragma unroll
-                for (int hb = 0; hb < NB; ++hb) {
-                    const long mb = rowbase + i * 32 + hb * PR;   // first row of this patch block
-                    f32x4_b rres[PASSES][2];
-                    if (EPI == 1) {                              // residual rows of the block, fetched before the LDS round trip
+                    for (int i = 0; i < TM; ++i) {
+                        const int r = jb * TM + i;
+                        const long mb = row0 + i * 32;                // first row of this round
+                        char* cu = reinterpret_cast<char*>(p.C) + (mb * p.ldc + p.c_coff + (n - ec)) * esz;            // uniform
+                        const char* ru = reinterpret_cast<const char*>(p.R) + (mb * p.ldr + p.r_coff + (n - ec)) * 2;   // flavour 0: bf16 residual
+                        if constexpr (M16) {
+#pragma unroll
+                            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                                for (int jj = 0; jj < EWN / 16; ++jj)
+                                    *reinterpret_cast<f32x4_b*>(wbase + ii * (16 * EWN * 4) + (((jj * 4) ^ wt) << 4)) = acc[2 * i + ii][jb * (EWN / 16) + jj];
+                        } else {
+#pragma unroll
+                            for (int jj = 0; jj < EWN / 32; ++jj)
+#pragma unroll
+                                for (int g = 0; g < 4; ++g) {
+                                    const auto& c = acc[i][jb * (EWN / 32) + jj];
+                                    const f32x4_b v = {c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]};
+                                    *reinterpret_cast<f32x4_b*>(wbase + (((jj * 8 + 2 * g) ^ wt) << 4)) = v;
+                                }
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_wave_barrier();
 #pragma unroll
                         for (int ps = 0; ps < PASSES; ++ps) {
-                            const long m = mb + ps * RPP + er;
-                            rres[ps][0] = zero4b(); rres[ps][1] = zero4b();
-                            if (p.R && m < p.M && n < p.N) {
-                                const float* rp = p.R + m * p.ldr + p.r_coff + n;
-                                rres[ps][0] = *reinterpret_cast<const f32x4_b*>(rp);
-                                rres[ps][1] = *reinterpret_cast<const f32x4_b*>(rp + 4);
+                            const int row = ps * RPP + er;
+                            const int sw = row & CM;
+                            const char* rb = wpatch + row * (EWN * 4);
+                            const f32x4_b v0 = *reinterpret_cast<const f32x4_b*>(rb + ((((ec >> 2)) ^ sw) << 4));
+                            const f32x4_b v1 = *reinterpret_cast<const f32x4_b*>(rb + ((((ec >> 2) + 1) ^ sw) << 4));
+                            const bool ok = FULL || (mb + row < p.M && nin);
+                            if constexpr (EPI == 2) {                // everything else: per element, correct, not fast
+                                if (ok) {
+                                    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                                    if (p.splitk > 1) {
+                                        float* dst = p.part + (long)e_slice * p.M * p.N + (mb + row) * p.N + n;
+#pragma unroll
+                                        for (int e = 0; e < 8; ++e) if (n + e < p.N) dst[e] = v[e];
+                                    } else {
+                                        float bias[8], sc[8], sh[8];
+#pragma unroll
+                                        for (int e = 0; e < 8; ++e) {
+                                            bias[e] = 0.f; sc[e] = 1.f; sh[e] = 0.f;
+                                            if (n + e < p.N) {
+                                                if (p.bias) bias[e] = p.bias[n + e];
+                                                if (has_scale) { sc[e] = p.scale[n + e]; sh[e] = p.shift[n + e]; }
+                                            }
+                                        }
+                                        store_row8<false>(p, (int)(mb + row), n, v, bias, sc, sh);
+                                    }
+                                }
+                                continue;
                             }
-                        }
-                    }
-#pragma unroll
-                    for (int jj = 0; jj < JPB; ++jj)
-#pragma unroll
-                        for (int r = hb * (16 / NB); r < (hb + 1) * (16 / NB); ++r) {
-                            const int prow = (r & 3) + 8 * ((r >> 2) % (PR >= 8 ? (PR / 8) : 1)) + rhalf;
-                            const int pcol = jj * 32 + col;
-                            patch[prow * EWN + ((((pcol >> 2) ^ (prow & 1)) << 2) | (pcol & 3))] = acc[i][jb * JPB + jj][r];
-                        }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int ps = 0; ps < PASSES; ++ps) {
-                        const int row = ps * RPP + er;
-                        const long m = mb + row;
-                        const int par = row & 1;
-                        const f32x4_b v0 = *reinterpret_cast<const f32x4_b*>(patch + row * EWN + (((ec >> 2) ^ par) << 2));
-                        const f32x4_b v1 = *reinterpret_cast<const f32x4_b*>(patch + row * EWN + ((((ec >> 2) + 1) ^ par) << 2));
-                        if (m >= p.M || n >= p.N) continue;
-                        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                        if (EPI == 2) {
-                            if (split) {
-                                float* dst = part + m * p.N + n;
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) if (n + e < p.N) dst[e] = v[e];
-                            } else {
-                                store_row8<false>(p, (int)m, n, v, bias, sc, sh);
+                            f32x4_b a = v0 + bias0, b = v1 + bias1;
+                            if (EPI == 0 && p.bbias) {               // per-image bias (the pooled ASPP branch folded into conv1)
+                                const long m = ok ? mb + row : 0;
+                                const float* bp = p.bbias + (m / p.bbias_rows) * p.N + nl;
+                                a = a + *reinterpret_cast<const f32x4_b*>(bp); b = b + *reinterpret_cast<const f32x4_b*>(bp + 4);
                             }
-                            continue;
-                        }
-                        // flavours 0 / 1: whole 8-column groups (the launcher checked N % 8 == 0 and the alignments)
-                        if (EPI == 0 && p.bbias) {               // per-image bias (the pooled ASPP branch folded into conv1)
-                            const float* bp = p.bbias + (m / p.bbias_rows) * p.N + n;
-                            const f32x4_b b0 = *reinterpret_cast<const f32x4_b*>(bp), b1 = *reinterpret_cast<const f32x4_b*>(bp + 4);
+                            if (SCALE) { a = a * sc0 + sh0; b = b * sc1 + sh1; }
+                            if (ACT == ACT_RELU) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-                        }
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            float tt = v[e] + bias[e];
-                            if (has_scale) tt = tt * sc[e] + sh[e];
-                            v[e] = tt;
-                        }
-                        if (act == ACT_RELU) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-                        } else if (act == ACT_GELU_ERF) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = EPI == 0 ? gelu_erf_bf16out(v[e]) : gelu_erf_b(v[e]);
-                        }
-                        if (EPI == 0) {
-                            if (p.R) {                           // bf16 residual (the decoder's lateral adds, in place)
-                                const u32x4_b rr = *reinterpret_cast<const u32x4_b*>(reinterpret_cast<const unsigned short*>(p.R) + m * p.ldr + p.r_coff + n);
+                                for (int e = 0; e < 4; ++e) { a[e] = fmaxf(a[e], 0.f); b[e] = fmaxf(b[e], 0.f); }
+                            } else if (ACT == ACT_GELU_ERF) {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
-                                    v[2 * e] += __builtin_bit_cast(float, rr[e] << 16);
-                                    v[2 * e + 1] += __builtin_bit_cast(float, rr[e] & 0xffff0000u);
+                                    a[e] = EPI == 0 ? gelu_erf_bf16out(a[e]) : gelu_erf_b(a[e]);
+                                    b[e] = EPI == 0 ? gelu_erf_bf16out(b[e]) : gelu_erf_b(b[e]);
                                 }
                             }
-                            bf16x8 o;
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
-                            *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.C) + m * p.ldc + p.c_coff + n) = o;
-                        } else {
-                            f32x4_b a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
-                            a = a + rres[ps][0];
-                            b = b + rres[ps][1];
-                            float* dst = p.C + m * p.ldc + p.c_coff + n;
-                            *reinterpret_cast<f32x4_b*>(dst) = a;
-                            *reinterpret_cast<f32x4_b*>(dst + 4) = b;
+                            char* cp = cu + (long)(ps * RPP) * p.ldc * esz + coff;
+                            if (EPI == 0) {
+                                if (p.R) {                           // bf16 residual (the decoder's lateral adds, in place)
+                                    const char* rp = ru + (long)(ps * RPP) * p.ldr * 2 + roff;
+                                    const u32x4_b rr = *reinterpret_cast<const u32x4_b*>(ok ? rp : reinterpret_cast<const char*>(g_zero_page));
+                                    a[0] += __builtin_bit_cast(float, rr[0] << 16); a[1] += __builtin_bit_cast(float, rr[0] & 0xffff0000u);
+                                    a[2] += __builtin_bit_cast(float, rr[1] << 16); a[3] += __builtin_bit_cast(float, rr[1] & 0xffff0000u);
+                                    b[0] += __builtin_bit_cast(float, rr[2] << 16); b[1] += __builtin_bit_cast(float, rr[2] & 0xffff0000u);
+                                    b[2] += __builtin_bit_cast(float, rr[3] << 16); b[3] += __builtin_bit_cast(float, rr[3] & 0xffff0000u);
+                                }
+                                const u32x4_b o = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
+                                if (!(abl & 16) || a[0] == 123.456f)  // diag bit 16: the epilogue without its stores
+                                if (ok) *reinterpret_cast<u32x4_b*>(cp) = o;
+                            } else {
+                                if (has_res1) { a = a + rres[ps][0]; b = b + rres[ps][1]; }
+                                if (ok) { *reinterpret_cast<f32x4_b*>(cp) = a; *reinterpret_cast<f32x4_b*>(cp + 16) = b; }
+                                if (has_res1 && r + 1 < NJB * TM) load_res(r + 1, ps);
+                            }
                         }
+                        __builtin_amdgcn_wave_barrier();              // the patch is rewritten by the next round
                     }
-                    __builtin_amdgcn_wave_barrier();              // the patch is rewritten by the next block
                 }
+            };
+            auto run_full = [&](auto act_c, auto scale_c) {
+                if (full) run(act_c, scale_c, std::true_type{}); else run(act_c, scale_c, std::false_type{});
+            };
+            using I0 = std::integral_constant<int, ACT_NONE>; using I1 = std::integral_constant<int, ACT_RELU>; using I2 = std::integral_constant<int, ACT_GELU_ERF>;
+            if constexpr (EPI == 2) run(I0{}, std::false_type{}, std::false_type{});
+            else if (has_scale) {
+                if (act == ACT_RELU) run_full(I1{}, std::true_type{});
+                else if (act == ACT_GELU_ERF) run_full(I2{}, std::true_type{});
+                else run_full(I0{}, std::true_type{});
+            } else {
+                if (act == ACT_RELU) run_full(I1{}, std::false_type{});
+                else if (act == ACT_GELU_ERF) run_full(I2{}, std::false_type{});
+                else run_full(I0{}, std::false_type{});
             }
         }
         // every wave of a FULL tile issued exactly STORES store instructions after the next item's first loads
@@ -491,7 +627,7 @@ __global__ void splitk_reduce_bf16_kernel(const GemmParams p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, int BBK = 64>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int BBK, bool M16 = BRN_BF16_MFMA16 != 0, bool BSINGLE = BRN_BF16_BSINGLE != 0>
 static hipError_t launch_bf16_cfg(const GemmParams& p, hipStream_t s) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.splitk;
     // persistent workgroups: as many as fit the chip at once (LDS-limited: NSTAGE ring slots each), never more than work items
@@ -504,7 +640,7 @@ static hipError_t launch_bf16_cfg(const GemmParams& p, hipStream_t s) {
     const bool plain = p.splitk == 1 && (p.N & 7) == 0;
     if (plain && !p.c_f32 && ((p.ldc | p.c_coff) & 7) == 0 && (!p.R || (!p.r_f32 && ((p.ldr | p.r_coff) & 7) == 0))) epi = 0;
     else if (plain && !p.bbias && p.c_f32 && ((p.ldc | p.c_coff) & 3) == 0 && (!p.R || (p.r_f32 && ((p.ldr | p.r_coff) & 3) == 0))) epi = 1;
-#define BRN_BF16_LAUNCH(MODE_, EPI_) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, NSTAGE, MODE_, BBK, EPI_>), grid, block, 0, s, p)
+#define BRN_BF16_LAUNCH(MODE_, EPI_) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, NSTAGE, MODE_, BBK, EPI_, M16, BSINGLE>), grid, block, 0, s, p)
     if (p.mode == GEMM_DENSE) {
         if (epi == 0) BRN_BF16_LAUNCH(GEMM_DENSE, 0); else if (epi == 1) BRN_BF16_LAUNCH(GEMM_DENSE, 1); else BRN_BF16_LAUNCH(GEMM_DENSE, 2);
     } else if (p.mode == GEMM_CONV_NHWC) {
@@ -514,22 +650,28 @@ static hipError_t launch_bf16_cfg(const GemmParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
-// Tile choice, from sweeps on MI355X (tools/gemm_bf16_sweep.py, profiles/r02_bf16_gemm_sweep.txt).  What bounds these kernels is the
-// L2 -> LDS intake of a CU (~68 GB/s measured with every CU streaming), not the matrix pipe, so the largest tile that still
-// fills the chip wins (bytes per flop halve from 128x128 to 256x256); small grids keep two or three independent 4-wave
-// workgroups per CU.  All K step 64, 2 ring slots, persistent workgroups:
+// Tile choice, from sweeps on MI355X (tools/gemm_bf16_sweep.py).  What bounds these kernels is the L2 -> LDS intake of a CU (~68 GB/s
+// measured with every CU streaming) and the clock the chip holds under MFMA load, so the largest tile that still fills the chip wins
+// (bytes per flop halve from 128x128 to 256x256); small grids keep two or three independent 4-wave workgroups per CU.  All K step
+// 64, 2 ring slots, persistent workgroups:
 //   cfg 0: 128x128, 4 waves (64 KB: 2 workgroups / CU)       cfg 1: 128x64, 4 waves (48 KB: 3 / CU)
-//   cfg 2: 256x256, 8 waves (128 KB: 1 / CU)                 cfg 3: 256x192, 8 waves (112 KB: 1 / CU; N = 192, 384, 576, 1152)
-struct Bf16Cfg { int cfg, bm, bn, slots; double eff; };
-static const Bf16Cfg kBf16Cfgs[] = {{0, 128, 128, 512, 0.88}, {1, 128, 64, 768, 0.72}, {2, 256, 256, 256, 1.00}, {3, 256, 192, 256, 0.92}};
-GemmPlan plan_gemm_bf16(int M, int N, int K) {
+//   cfg 2: 256x256, 8 waves (128 KB: 1 / CU), 32x32x16       cfg 3: 256x192, 8 waves (112 KB: 1 / CU)
+// eff = measured throughput of a full-chip launch relative to cfg 2 (same box, round 2: 16x16x32 lifted cfg 0 / 1 / 3 by 5-13 %);
+// cfg 3 loses to cfg 2 on long K (its intake per flop is 17 % higher), wins on short K and wherever it divides N or the grid better.
+struct Bf16Cfg { int cfg, bm, bn, slots; double eff, eff_long_k; };
+static const Bf16Cfg kBf16Cfgs[] = {{0, 128, 128, 512, 0.92, 0.88}, {1, 128, 64, 768, 0.76, 0.74}, {2, 256, 256, 256, 1.00, 1.00}, {3, 256, 192, 256, 1.00, 0.90}};
+GemmPlan plan_gemm_bf16(int M, int N, int K, bool f32_residual) {
     GemmPlan pl{0, 1, 0};
     double best = 1e300;
     long best_tiles = 1;
     for (const Bf16Cfg& c : kBf16Cfgs) {
         const long tiles = (long)((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn);
         // a launch lasts ~ rounds x (tile area x workgroups sharing a CU) / relative CU throughput of the config
-        const double cost = (double)((tiles + c.slots - 1) / c.slots) * (c.slots / 256) * c.bm * c.bn / c.eff;
+        double eff = K > 1536 ? c.eff_long_k : c.eff;
+        // (f32_residual — proj / fc2 — is a hint without effect for now: two workgroups per CU measured 4 % faster in isolation on
+        // the proj shape and 8 % slower inside the model, where A comes straight out of the attention kernel)
+        (void)f32_residual;
+        const double cost = (double)((tiles + c.slots - 1) / c.slots) * (c.slots / 256) * c.bm * c.bn / eff;
         if (cost < best) { best = cost; pl.cfg = c.cfg; best_tiles = tiles; }
     }
     const int nk = (K + 63) / 64;
@@ -556,7 +698,7 @@ hipError_t launch_gemm_bf16(const GemmParams& p_in, const GemmPlan& pl, float* w
     if (p.splitk > 1 && !ws) return hipErrorInvalidValue;
     hipError_t e;
     if (pl.cfg == 1) e = launch_bf16_cfg<128, 64, 2, 2, 2, 64>(p, s);
-    else if (pl.cfg == 2) e = launch_bf16_cfg<256, 256, 4, 2, 2, 64>(p, s);
+    else if (pl.cfg == 2) e = launch_bf16_cfg<256, 256, 4, 2, 2, 64, BRN_BF16_CFG2_M16 != 0, BRN_BF16_CFG2_M16 != 0>(p, s);
     else if (pl.cfg == 3) e = launch_bf16_cfg<256, 192, 4, 2, 2, 64>(p, s);
 #ifdef BRN_DIAG_BUILD          // candidates kept for sweeps (tools/gemm_bf16_sweep.py)
     else if (pl.cfg == 10) e = launch_bf16_cfg<128, 128, 2, 2, 3, 32>(p, s);

@@ -405,37 +405,58 @@ __device__ __forceinline__ bf16x8 bias8_bf16(const float* bp) {
     return r;
 }
 
-__global__ void __launch_bounds__(ATT_THREADS) window_attention_bf16_kernel(const WindowAttnParams pa, const WindowAttnParams pb, const int nblk0) {
+__global__ void __launch_bounds__(ATT_THREADS) __attribute__((amdgpu_num_vgpr(96))) window_attention_bf16_kernel(const WindowAttnParams pa, const WindowAttnParams pb, const int nblk0) {
     const bool second = (int)blockIdx.x >= nblk0;
     const WindowAttnParams& p = second ? pb : pa;
+    constexpr int TABN = (2 * WS - 1) * (2 * WS - 1);                 // 529
+    constexpr float LOG2E = 1.4426950408889634f;
     __shared__ __attribute__((aligned(16))) __bf16 Kp[NTOK * HD];
     __shared__ __attribute__((aligned(16))) __bf16 Vt[HD * VT_LD];
-    __shared__ float tab_s[(2 * WS - 1) * (2 * WS - 1)];
+    // this head's bias table REVERSED and in log2 units: rev[j] = log2(e) * table[528 - j].  The 4 keys 16 kt + 4 g + {0..3} of a lane
+    // lie in one window row (12 % 4 == 0), so their table entries are 4 consecutive words of rev: one index per key tile
+    // instead of one per score (the index arithmetic was most of the softmax's VALU work).
+    __shared__ float rev_s[TABN + 3];
     __shared__ int src_s[NTOK];
-    __shared__ unsigned char rid_s[NTOK];
+    __shared__ __attribute__((aligned(4))) unsigned char rid_s[NTOK];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int head = blockIdx.y;
-    const int nWw = p.Wp / WS, nW = (p.Hp / WS) * nWw;
+    const int nWh = p.Hp / WS, nWw = p.Wp / WS, nW = nWh * nWw;
     const int bw = second ? (int)blockIdx.x - nblk0 : (int)blockIdx.x;
     const int b = bw / nW, w = bw - b * nW;
     const int wr = w / nWw, wc = w - wr * nWw;
     const int C = p.C, C3 = 3 * C;
     const __bf16* qkv = reinterpret_cast<const __bf16*>(p.qkv);
+    const int li = lane & 15, g = lane >> 4;
+    // the shift mask (swin.rs:283-296) is non-zero only in the last row / column of windows
+    const bool has_mask = p.shift > 0 && (wr == nWh - 1 || wc == nWw - 1);
 
+    auto tok_src = [&](int t) {                                       // source row of window token t (roll + partition), -1 = pad token
+        const int ti = t / WS, tj = t - ti * WS;
+        int sh = wr * WS + ti + p.shift, sw = wc * WS + tj + p.shift;
+        if (sh >= p.Hp) sh -= p.Hp;
+        if (sw >= p.Wp) sw -= p.Wp;
+        return (sh < p.H && sw < p.W) ? (b * p.H + sh) * p.W + sw : -1;
+    };
+    // ---- this wave's three Q fragments first: their latency hides behind the K / V staging ----
+    bf16x8 qf[3];
+    int qsrc_[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int qs = tok_src((wave + 3 * u) * 16 + li);
+        qsrc_[u] = qs;
+        if (qs >= 0) qf[u] = *reinterpret_cast<const bf16x8*>(qkv + (long)qs * C3 + head * HD + g * 8);
+        else qf[u] = bias8_bf16(p.qkv_bias + head * HD + g * 8);
+    }
     if (tid < NTOK) {
         const int ti = tid / WS, tj = tid - ti * WS;
         const int ph = wr * WS + ti, pw = wc * WS + tj;
-        int sh = ph + p.shift, sw = pw + p.shift;
-        if (sh >= p.Hp) sh -= p.Hp;
-        if (sw >= p.Wp) sw -= p.Wp;
-        src_s[tid] = (sh < p.H && sw < p.W) ? (b * p.H + sh) * p.W + sw : -1;
+        src_s[tid] = tok_src(tid);
         const int fh = ph < p.Hp - WS ? 0 : (ph < p.Hp - p.shift ? 1 : 2);
         const int fw = pw < p.Wp - WS ? 0 : (pw < p.Wp - p.shift ? 1 : 2);
         rid_s[tid] = (unsigned char)(fh * 3 + fw);
     }
-    for (int i = tid; i < (2 * WS - 1) * (2 * WS - 1); i += ATT_THREADS) tab_s[i] = p.rel_table[head * ((2 * WS - 1) * (2 * WS - 1)) + i];
-    __syncthreads();
+    for (int i = tid; i < TABN; i += ATT_THREADS) rev_s[i] = LOG2E * p.rel_table[head * TABN + (TABN - 1 - i)];
 
     // ---- stage K (row-major, chunk-swizzled) and V (transposed): items = (token pair, 8-wide d chunk) ----
     for (int idx = tid; idx < (NTOK / 2) * 4; idx += ATT_THREADS) {
@@ -443,7 +464,7 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_bf16_kernel(cons
         bf16x8 kv[2], vv[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int t = tp * 2 + u, src = src_s[t];
+            const int t = tp * 2 + u, src = tok_src(t);
             if (src >= 0) {
                 const __bf16* kp = qkv + (long)src * C3 + C + head * HD + c8;
                 kv[u] = *reinterpret_cast<const bf16x8*>(kp);
@@ -467,36 +488,45 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_bf16_kernel(cons
     }
     __syncthreads();
 
-    const int li = lane & 15, g = lane >> 4;
-    for (int qt = wave; qt < 9; qt += 3) {
+    const float scale2 = p.scale * LOG2E;
+    // per key tile: koff = key0 + 11 (key0 / 12) for key0 = 16 kt + 4 g; the table word of (query, key0 + r) is rev[qrev + koff + r]
+    int koff[9];
+#pragma unroll
+    for (int kt = 0; kt < 9; ++kt) { const int key0 = kt * 16 + g * 4; koff[kt] = key0 + 11 * (key0 / WS); }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int qt = wave + 3 * u;
         const int qtok = qt * 16 + li;
-        const int qsrc = src_s[qtok];
+        const int qsrc = qsrc_[u];
         const int qrid = rid_s[qtok];
-        const int qbase = (qtok / WS + WS - 1) * (2 * WS - 1) + (qtok % WS) + WS - 1;
-        bf16x8 qf;
-        if (qsrc >= 0) qf = *reinterpret_cast<const bf16x8*>(qkv + (long)qsrc * C3 + head * HD + g * 8);
-        else qf = bias8_bf16(p.qkv_bias + head * HD + g * 8);
+        // table index of (query, key) = qbase - key - 11 (key / 12), qbase = (qi + 11) 23 + qj + 11 (swin.rs:143-152 arithmetically)
+        const int qrev = (TABN - 1) - ((qtok / WS + WS - 1) * (2 * WS - 1) + (qtok % WS) + WS - 1);
         f32x4 st[9];
 #pragma unroll
         for (int kt = 0; kt < 9; ++kt) {
             const int key = kt * 16 + li;
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kp + key * HD + ((g ^ kswz(key)) << 3));
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, acc, 0, 0, 0);
+            st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[u], acc, 0, 0, 0);
             if (kt % 3 == 2) __builtin_amdgcn_sched_barrier(0);
         }
         float mx = -3.0e38f;
 #pragma unroll
         for (int kt = 0; kt < 9; ++kt) {
+            const float* tb = rev_s + qrev + koff[kt];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt * 16 + g * 4 + r;
-                float sv = st[kt][r] * p.scale + tab_s[qbase - key - 11 * (key / WS)];
-                if (p.shift > 0) sv += ((int)rid_s[key] != qrid) ? -100.0f : 0.0f;
-                st[kt][r] = sv;
-                mx = fmaxf(mx, sv);
+            for (int r = 0; r < 4; ++r) st[kt][r] = fmaf(st[kt][r], scale2, tb[r]);
+        }
+        if (has_mask) {
+#pragma unroll
+            for (int kt = 0; kt < 9; ++kt) {
+                const unsigned rw = *reinterpret_cast<const unsigned*>(rid_s + kt * 16 + g * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[kt][r] += ((int)((rw >> (8 * r)) & 0xffu) != qrid) ? -100.0f * LOG2E : 0.0f;
             }
         }
+#pragma unroll
+        for (int kt = 0; kt < 9; ++kt) mx = fmaxf(fmaxf(mx, fmaxf(st[kt][0], st[kt][1])), fmaxf(st[kt][2], st[kt][3]));
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         float sum = 0.f;
@@ -504,7 +534,7 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_bf16_kernel(cons
         for (int kt = 0; kt < 9; ++kt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = __expf(st[kt][r] - mx);
+                const float e = __builtin_amdgcn_exp2f(st[kt][r] - mx);
                 st[kt][r] = e;
                 sum += e;
             }
