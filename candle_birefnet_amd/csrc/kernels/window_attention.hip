@@ -22,6 +22,7 @@
 //                               the same key permutation.  No transpose, no LDS round trip for P.
 #include "../brn_kernels.h"
 #include "split_planes.h"
+#include <cstdlib>
 
 namespace brn {
 
@@ -405,22 +406,25 @@ __device__ __forceinline__ bf16x8 bias8_bf16(const float* bp) {
     return r;
 }
 
-__global__ void __launch_bounds__(ATT_THREADS) __attribute__((amdgpu_num_vgpr(96))) window_attention_bf16_kernel(const WindowAttnParams pa, const WindowAttnParams pb, const int nblk0) {
+// Two heads per workgroup (6 waves: waves 0-2 head 2y, waves 3-5 head 2y + 1): a token's K (or V) rows of two adjacent heads are one
+// 128-byte line, so the staging loads fetch whole lines (one head per workgroup used half of every line it touched).
+template <int ATT_BF16_HPW>
+__global__ void __launch_bounds__(ATT_BF16_HPW * ATT_THREADS) __attribute__((amdgpu_waves_per_eu(5, 8))) window_attention_bf16_kernel(const WindowAttnParams pa, const WindowAttnParams pb, const int nblk0) {
     const bool second = (int)blockIdx.x >= nblk0;
     const WindowAttnParams& p = second ? pb : pa;
     constexpr int TABN = (2 * WS - 1) * (2 * WS - 1);                 // 529
     constexpr float LOG2E = 1.4426950408889634f;
-    __shared__ __attribute__((aligned(16))) __bf16 Kp[NTOK * HD];
-    __shared__ __attribute__((aligned(16))) __bf16 Vt[HD * VT_LD];
-    // this head's bias table REVERSED and in log2 units: rev[j] = log2(e) * table[528 - j].  The 4 keys 16 kt + 4 g + {0..3} of a lane
+    __shared__ __attribute__((aligned(16))) __bf16 Kp_[ATT_BF16_HPW][NTOK * HD];
+    __shared__ __attribute__((aligned(16))) __bf16 Vt_[ATT_BF16_HPW][HD * VT_LD];
+    // a head's bias table REVERSED and in log2 units: rev[j] = log2(e) * table[528 - j].  The 4 keys 16 kt + 4 g + {0..3} of a lane
     // lie in one window row (12 % 4 == 0), so their table entries are 4 consecutive words of rev: one index per key tile
     // instead of one per score (the index arithmetic was most of the softmax's VALU work).
-    __shared__ float rev_s[TABN + 3];
-    __shared__ int src_s[NTOK];
+    __shared__ float rev_[ATT_BF16_HPW][TABN + 3];
     __shared__ __attribute__((aligned(4))) unsigned char rid_s[NTOK];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int head = blockIdx.y;
+    const int hp = wave / 3, wv = wave - 3 * hp;                      // head of the pair, wave within the head
+    const int head = blockIdx.y * ATT_BF16_HPW + hp;
     const int nWh = p.Hp / WS, nWw = p.Wp / WS, nW = nWh * nWw;
     const int bw = second ? (int)blockIdx.x - nblk0 : (int)blockIdx.x;
     const int b = bw / nW, w = bw - b * nW;
@@ -430,6 +434,9 @@ __global__ void __launch_bounds__(ATT_THREADS) __attribute__((amdgpu_num_vgpr(96
     const int li = lane & 15, g = lane >> 4;
     // the shift mask (swin.rs:283-296) is non-zero only in the last row / column of windows
     const bool has_mask = p.shift > 0 && (wr == nWh - 1 || wc == nWw - 1);
+    __bf16* Kp = Kp_[hp];
+    __bf16* Vt = Vt_[hp];
+    const float* rev_s = rev_[hp];
 
     auto tok_src = [&](int t) {                                       // source row of window token t (roll + partition), -1 = pad token
         const int ti = t / WS, tj = t - ti * WS;
@@ -443,7 +450,7 @@ __global__ void __launch_bounds__(ATT_THREADS) __attribute__((amdgpu_num_vgpr(96
     int qsrc_[3];
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
-        const int qs = tok_src((wave + 3 * u) * 16 + li);
+        const int qs = tok_src((wv + 3 * u) * 16 + li);
         qsrc_[u] = qs;
         if (qs >= 0) qf[u] = *reinterpret_cast<const bf16x8*>(qkv + (long)qs * C3 + head * HD + g * 8);
         else qf[u] = bias8_bf16(p.qkv_bias + head * HD + g * 8);
@@ -451,39 +458,43 @@ __global__ void __launch_bounds__(ATT_THREADS) __attribute__((amdgpu_num_vgpr(96
     if (tid < NTOK) {
         const int ti = tid / WS, tj = tid - ti * WS;
         const int ph = wr * WS + ti, pw = wc * WS + tj;
-        src_s[tid] = tok_src(tid);
         const int fh = ph < p.Hp - WS ? 0 : (ph < p.Hp - p.shift ? 1 : 2);
         const int fw = pw < p.Wp - WS ? 0 : (pw < p.Wp - p.shift ? 1 : 2);
         rid_s[tid] = (unsigned char)(fh * 3 + fw);
     }
-    for (int i = tid; i < TABN; i += ATT_THREADS) rev_s[i] = LOG2E * p.rel_table[head * TABN + (TABN - 1 - i)];
+    for (int i = tid; i < ATT_BF16_HPW * TABN; i += (ATT_BF16_HPW * ATT_THREADS)) {
+        const int hh = i / TABN, j = i - hh * TABN;
+        rev_[hh][j] = LOG2E * p.rel_table[(blockIdx.y * ATT_BF16_HPW + hh) * TABN + (TABN - 1 - j)];
+    }
 
-    // ---- stage K (row-major, chunk-swizzled) and V (transposed): items = (token pair, 8-wide d chunk) ----
-    for (int idx = tid; idx < (NTOK / 2) * 4; idx += ATT_THREADS) {
-        const int tp = idx >> 2, c8 = (idx & 3) * 8;
+    // ---- stage K (row-major, chunk-swizzled) and V (transposed): items = (token pair, head of the pair, 8-wide d chunk); 8 consecutive
+    // threads fetch the 128 contiguous bytes that hold one token's K (V) rows of both heads ----
+    for (int idx = tid; idx < (NTOK / 2) * 4 * ATT_BF16_HPW; idx += (ATT_BF16_HPW * ATT_THREADS)) {
+        const int c8 = (idx & 3) * 8, hh = (idx >> 2) & (ATT_BF16_HPW - 1), tp = idx >> 3;
+        const int hd = (blockIdx.y * ATT_BF16_HPW + hh) * HD;
         bf16x8 kv[2], vv[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int t = tp * 2 + u, src = tok_src(t);
             if (src >= 0) {
-                const __bf16* kp = qkv + (long)src * C3 + C + head * HD + c8;
+                const __bf16* kp = qkv + (long)src * C3 + C + hd + c8;
                 kv[u] = *reinterpret_cast<const bf16x8*>(kp);
                 vv[u] = *reinterpret_cast<const bf16x8*>(kp + C);
             } else {          // pad token: LayerNorm output row is zero, so q / k / v = the qkv bias (swin.rs:359-366)
-                kv[u] = bias8_bf16(p.qkv_bias + C + head * HD + c8);
-                vv[u] = bias8_bf16(p.qkv_bias + 2 * C + head * HD + c8);
+                kv[u] = bias8_bf16(p.qkv_bias + C + hd + c8);
+                vv[u] = bias8_bf16(p.qkv_bias + 2 * C + hd + c8);
             }
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int t = tp * 2 + u;
-            *reinterpret_cast<bf16x8*>(Kp + t * HD + (((c8 >> 3) ^ kswz(t)) << 3)) = kv[u];
+            *reinterpret_cast<bf16x8*>(Kp_[hh] + t * HD + (((c8 >> 3) ^ kswz(t)) << 3)) = kv[u];
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             bf16x2 h;
             h[0] = vv[0][e]; h[1] = vv[1][e];
-            *reinterpret_cast<bf16x2*>(Vt + (c8 + e) * VT_LD + tp * 2) = h;
+            *reinterpret_cast<bf16x2*>(Vt_[hh] + (c8 + e) * VT_LD + tp * 2) = h;
         }
     }
     __syncthreads();
@@ -495,7 +506,7 @@ __global__ void __launch_bounds__(ATT_THREADS) __attribute__((amdgpu_num_vgpr(96
     for (int kt = 0; kt < 9; ++kt) { const int key0 = kt * 16 + g * 4; koff[kt] = key0 + 11 * (key0 / WS); }
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
-        const int qt = wave + 3 * u;
+        const int qt = wv + 3 * u;
         const int qtok = qt * 16 + li;
         const int qsrc = qsrc_[u];
         const int qrid = rid_s[qtok];
@@ -599,7 +610,11 @@ hipError_t launch_window_attention2(const WindowAttnParams& p, const WindowAttnP
     dim3 grid(n0 + n1, p.heads), block(ATT_THREADS);
     if (p.io_bf16) {
         if (p.out_planes || (p.C & 7)) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(window_attention_bf16_kernel, grid, block, 0, s, p, q, n0);
+        // two heads per workgroup (whole 128-byte lines per token in the staging loads) measured 5 % SLOWER end to end (225 vs 237
+        // img/s at batch 8, tools/bench_env_ab.py BRN_ATT_HPW=1|2): kept behind the switch, one head per workgroup is the default
+        static const bool two_heads = getenv("BRN_ATT_HPW") && atoi(getenv("BRN_ATT_HPW")) == 2;
+        if (two_heads && !(p.heads & 1)) hipLaunchKernelGGL(window_attention_bf16_kernel<2>, dim3(n0 + n1, p.heads / 2), dim3(2 * ATT_THREADS), 0, s, p, q, n0);
+        else hipLaunchKernelGGL(window_attention_bf16_kernel<1>, grid, block, 0, s, p, q, n0);
     } else if (p.planes == 2) hipLaunchKernelGGL(window_attention_split_kernel<2>, grid, block, 0, s, p, q, n0);
     else if (p.planes == 1) hipLaunchKernelGGL(window_attention_split_kernel<1>, grid, block, 0, s, p, q, n0);
     else if (ws == 7) hipLaunchKernelGGL(window_attention_f32_kernel<7>, grid, block, 0, s, p, q, n0);
