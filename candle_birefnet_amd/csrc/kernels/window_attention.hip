@@ -470,7 +470,7 @@ __global__ void __launch_bounds__(ATT_BF16_HPW * ATT_THREADS) __attribute__((amd
     // ---- stage K (row-major, chunk-swizzled) and V (transposed): items = (token pair, head of the pair, 8-wide d chunk); 8 consecutive
     // threads fetch the 128 contiguous bytes that hold one token's K (V) rows of both heads ----
     for (int idx = tid; idx < (NTOK / 2) * 4 * ATT_BF16_HPW; idx += (ATT_BF16_HPW * ATT_THREADS)) {
-        const int c8 = (idx & 3) * 8, hh = (idx >> 2) & (ATT_BF16_HPW - 1), tp = idx >> 3;
+        const int c8 = (idx & 3) * 8, hh = (idx >> 2) & (ATT_BF16_HPW - 1), tp = idx / (4 * ATT_BF16_HPW);
         const int hd = (blockIdx.y * ATT_BF16_HPW + hh) * HD;
         bf16x8 kv[2], vv[2];
 #pragma unroll
@@ -610,7 +610,7 @@ hipError_t launch_window_attention2(const WindowAttnParams& p, const WindowAttnP
     dim3 grid(n0 + n1, p.heads), block(ATT_THREADS);
     if (p.io_bf16) {
         if (p.out_planes || (p.C & 7)) return hipErrorInvalidValue;
-        // two heads per workgroup (whole 128-byte lines per token in the staging loads) measured 5 % SLOWER end to end (225 vs 237
+        // two heads per workgroup (whole 128-byte lines per token in the staging loads) measured 1 % slower end to end (224.5 vs 226.8
         // img/s at batch 8, tools/bench_env_ab.py BRN_ATT_HPW=1|2): kept behind the switch, one head per workgroup is the default
         static const bool two_heads = getenv("BRN_ATT_HPW") && atoi(getenv("BRN_ATT_HPW")) == 2;
         if (two_heads && !(p.heads & 1)) hipLaunchKernelGGL(window_attention_bf16_kernel<2>, dim3(n0 + n1, p.heads / 2), dim3(2 * ATT_THREADS), 0, s, p, q, n0);
