@@ -133,7 +133,7 @@ brn_status brn_gemm_microbench(int M, int N, int K, int tile_cfg, int splitk, in
             const bool epi1 = getenv("BRN_GEMM_EPI1") != nullptr;      // fp32 C + fp32 residual in place (proj / fc2) instead of bf16 C
             std::vector<float> hc(epi1 ? (size_t)M * N : (size_t)M * N / 2 + 64, 0.f);
             float* dC = own.upload(hc);
-            GemmPlan pl = plan_gemm_bf16(M, N, K, epi1);
+            GemmPlan pl = plan_gemm_bf16(M, N, K, epi1, getenv("BRN_GEMM_ACT") && atoi(getenv("BRN_GEMM_ACT")) == 2);
             if (tile_cfg >= 0) { pl.cfg = tile_cfg; pl.splitk = splitk > 1 ? splitk : 1; pl.ws_floats = pl.splitk > 1 ? (size_t)pl.splitk * M * N : 0; }
             float* ws = nullptr;
             if (pl.ws_floats) { std::vector<float> z(pl.ws_floats, 0.f); ws = own.upload(z); }

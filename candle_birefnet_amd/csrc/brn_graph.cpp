@@ -61,7 +61,7 @@ static void fill_epilogue(GemmParams& p, const GemmW& w) {
 // bf16-storage mode: the same GEMM on kernels/gemm_bf16.hip (A bf16; C / R bf16 unless flagged fp32)
 static void run_gemm_bf16(Ctx& c, const GemmW& w, GemmParams& p, int fam) {
     if (!w.wb) fail(BRN_ERR_INVALID_ARG, "bf16 mode: weight without a bf16 copy");
-    const GemmPlan pl = plan_gemm_bf16(p.M, p.N, p.K, p.c_f32 && p.R && p.r_f32);
+    const GemmPlan pl = plan_gemm_bf16(p.M, p.N, p.K, p.c_f32 && p.R && p.r_f32, p.act == ACT_GELU_ERF);
     const size_t mk = c.arena->mark();
     float* ws = pl.ws_floats ? c.arena->alloc(pl.ws_floats) : nullptr;
     c.arena->release(mk);

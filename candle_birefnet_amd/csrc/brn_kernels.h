@@ -56,7 +56,7 @@ GemmPlan plan_gemm(int M, int N, int K, int planes = 0);   // planes: bf16 plane
 hipError_t launch_gemm(const GemmParams& p, const GemmPlan& plan, float* ws, hipStream_t s);
 
 // bf16-storage mode: plan + launch (kernels/gemm_bf16.hip).  cfg: 0 = 128x128, 1 = 128x64, 2 = 256x256, 3 = 256x192 block tile
-GemmPlan plan_gemm_bf16(int M, int N, int K, bool f32_residual = false);   // f32_residual: fp32 C with an fp32 residual (proj / fc2)
+GemmPlan plan_gemm_bf16(int M, int N, int K, bool f32_residual = false, bool gelu = false);   // f32_residual: fp32 C with an fp32 residual (proj / fc2)
 hipError_t launch_gemm_bf16(const GemmParams& p, const GemmPlan& plan, float* ws, hipStream_t s);
 
 // split modes with A already in the P layout (kernels/gemm_planes.hip): LDS-DMA staged, persistent, no splitting wave
