@@ -352,7 +352,8 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
             constexpr bool STAGE_NEXT = decltype(stage_next)::value;
             // K step t has landed once at most `after` younger steps (and, at t = 0, the previous item's stores) are outstanding
             const int after = min(nt - 1, t + NSTAGE - 2) - t;
-            if (t == 0 && counted && after == NSTAGE - 2) wait_vmcnt<(NSTAGE - 2) * LPS + STORES>();
+            constexpr int VM0 = (NSTAGE - 2) * LPS + STORES > 63 ? 63 : (NSTAGE - 2) * LPS + STORES;   // (the counter has 6 bits; a smaller N only waits longer)
+            if (t == 0 && counted && after == NSTAGE - 2) wait_vmcnt<VM0>();
             else if (NSTAGE >= 4 && after >= 2) wait_vmcnt<2 * LPS>();
             else if (NSTAGE >= 3 && after >= 1) wait_vmcnt<LPS>();
             else wait_vmcnt<0>();
