@@ -70,7 +70,15 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_f32_kernel(const
         const int fw = pw < p.Wp - WS ? 0 : (pw < p.Wp - p.shift ? 1 : 2);
         rid_s[tid] = fh * 3 + fw;
     } else if (tid < NPADTOK) { src_s[tid] = -1; rid_s[tid] = 0; }
-    for (int i = tid; i < (2 * WS - 1) * (2 * WS - 1); i += ATT_THREADS) tab_s[i] = p.rel_table[head * ((2 * WS - 1) * (2 * WS - 1)) + i];
+    // window 12: the table is kept REVERSED and in log2 units (tab_s[j] = log2(e) * table[528 - j]): the 4 keys 16 kt + 4 g + {0..3} of
+    // a lane lie in one window row (12 % 4 == 0), so their entries are 4 consecutive words — one index per key tile instead of
+    // one per score — and the softmax runs on exp2.  Window 7 keeps the plain table and the per-score index.
+    constexpr int TABN = (2 * WS - 1) * (2 * WS - 1);
+    constexpr bool REV = WS == 12;
+    constexpr float LOG2E = 1.4426950408889634f;
+    for (int i = tid; i < TABN; i += ATT_THREADS) tab_s[i] = REV ? LOG2E * p.rel_table[head * TABN + (TABN - 1 - i)] : p.rel_table[head * TABN + i];
+    // the shift mask (swin.rs:283-296) is non-zero only in the last row / column of windows
+    const bool has_mask = p.shift > 0 && (wr == p.Hp / WS - 1 || wc == nWw - 1);
     __syncthreads();
 
     // ---- stage K and V of this (window, head) into LDS: 144 rows x 8 float4 each ----
@@ -88,6 +96,16 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_f32_kernel(const
 
     const int li = lane & 15, g = lane >> 4;
 
+    // the Q fragment of the NEXT query tile is requested while this one is multiplied (8 registers; fetching all three up front
+    // cost occupancy and was slower)
+    auto load_q = [&](int qt, f32x4& q0, f32x4& q1) {
+        const int qs = src_s[qt * 16 + li];
+        const float* qp = qs >= 0 ? p.qkv + (long)qs * C3 + head * HD + g * 8 : p.qkv_bias + head * HD + g * 8;
+        q0 = *reinterpret_cast<const f32x4*>(qp);
+        q1 = *reinterpret_cast<const f32x4*>(qp + 4);
+    };
+    f32x4 qn0 = {0.f, 0.f, 0.f, 0.f}, qn1 = qn0;
+    if (wave < NT16) load_q(wave, qn0, qn1);
     for (int qt = wave; qt < NT16; qt += 3) {
         const int qtok = qt * 16 + li;
         const int qsrc = src_s[qtok];
@@ -97,13 +115,9 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_f32_kernel(const
         const int qbase = (qt_ / WS + WS - 1) * (2 * WS - 1) + (qt_ % WS) + WS - 1;
         // Q fragment: d = 8g .. 8g+7 of query row qtok, scaled before the product (swin.rs:278)
         float qf[8];
-        {
-            const float* qp = qsrc >= 0 ? p.qkv + (long)qsrc * C3 + head * HD + g * 8 : p.qkv_bias + head * HD + g * 8;
-            const f32x4 q0 = *reinterpret_cast<const f32x4*>(qp);
-            const f32x4 q1 = *reinterpret_cast<const f32x4*>(qp + 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { qf[e] = q0[e] * p.scale; qf[4 + e] = q1[e] * p.scale; }
-        }
+        for (int e = 0; e < 4; ++e) { qf[e] = qn0[e] * p.scale; qf[4 + e] = qn1[e] * p.scale; }
+        if (qt + 3 < NT16) load_q(qt + 3, qn0, qn1);
         // S^T = K . Q^T : 9 key tiles
         f32x4 st[NT16];
 #pragma unroll
@@ -121,17 +135,37 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_f32_kernel(const
         }
         // + relative position bias (swin.rs:284-285), + SW-MSA mask (swin.rs:288-297, value -100 swin.rs:651)
         float mx = -3.0e38f;
+        if constexpr (REV) {
+            const int qrev = (TABN - 1) - qbase;
 #pragma unroll
-        for (int kt = 0; kt < NT16; ++kt) {
+            for (int kt = 0; kt < NT16; ++kt) {
+                const int key0 = kt * 16 + g * 4;
+                const float* tb = tab_s + qrev + key0 + (WS - 1) * (key0 / WS);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt * 16 + g * 4 + r;
-                const int kk = key < NTOK ? key : 0;
-                float s = st[kt][r] + tab_s[max(0, qbase - kk - (WS - 1) * (kk / WS))];
-                if (p.shift > 0) s += (rid_s[key] != qrid) ? -100.0f : 0.0f;
-                if (NTOK % 16 != 0 && key >= NTOK) s = -3.0e38f;
-                st[kt][r] = s;
-                mx = fmaxf(mx, s);
+                for (int r = 0; r < 4; ++r) st[kt][r] = fmaf(st[kt][r], LOG2E, tb[r]);
+            }
+            if (has_mask) {
+#pragma unroll
+                for (int kt = 0; kt < NT16; ++kt) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st[kt][r] += (rid_s[kt * 16 + g * 4 + r] != qrid) ? -100.0f * LOG2E : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int kt = 0; kt < NT16; ++kt) mx = fmaxf(fmaxf(mx, fmaxf(st[kt][0], st[kt][1])), fmaxf(st[kt][2], st[kt][3]));
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < NT16; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * 16 + g * 4 + r;
+                    const int kk = key < NTOK ? key : 0;
+                    float s = st[kt][r] + tab_s[max(0, qbase - kk - (WS - 1) * (kk / WS))];
+                    if (p.shift > 0) s += (rid_s[key] != qrid) ? -100.0f : 0.0f;
+                    if (NTOK % 16 != 0 && key >= NTOK) s = -3.0e38f;
+                    st[kt][r] = s;
+                    mx = fmaxf(mx, s);
+                }
             }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16));
@@ -141,7 +175,7 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_f32_kernel(const
         for (int kt = 0; kt < NT16; ++kt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = __expf(st[kt][r] - mx);
+                const float e = REV ? __builtin_amdgcn_exp2f(st[kt][r] - mx) : __expf(st[kt][r] - mx);
                 st[kt][r] = e;
                 sum += e;
             }
