@@ -67,11 +67,44 @@ __global__ void resize_nhwc_kernel(const T* __restrict__ x, int B, int Hin, int 
     }
 }
 
+// bf16 maps, 8 channels (16 bytes) per lane: same arithmetic per element as the 4-wide form, half the memory instructions
+__global__ void resize_nhwc_bf16x8_kernel(const __bf16* __restrict__ x, int B, int Hin, int Win, int C8, int ldx, int x_coff,
+                                          __bf16* __restrict__ y, int Hout, int Wout, int ldy, int y_coff) {
+    typedef __bf16 bf16x8_e __attribute__((ext_vector_type(8)));
+    const size_t total = (size_t)B * Hout * Wout * C8;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(idx % C8);
+        size_t pix = idx / C8;
+        const int ox = (int)(pix % Wout); pix /= Wout;
+        const int oy = (int)(pix % Hout);
+        const int b = (int)(pix / Hout);
+        int y0, y1, x0, x1; float ly, lx;
+        ac_coord(oy, Hin, Hout, y0, y1, ly);
+        ac_coord(ox, Win, Wout, x0, x1, lx);
+        const __bf16* base = x + (size_t)b * Hin * Win * ldx + x_coff + c8 * 8;
+        const bf16x8_e v00 = *reinterpret_cast<const bf16x8_e*>(base + ((size_t)y0 * Win + x0) * ldx);
+        const bf16x8_e v01 = *reinterpret_cast<const bf16x8_e*>(base + ((size_t)y0 * Win + x1) * ldx);
+        const bf16x8_e v10 = *reinterpret_cast<const bf16x8_e*>(base + ((size_t)y1 * Win + x0) * ldx);
+        const bf16x8_e v11 = *reinterpret_cast<const bf16x8_e*>(base + ((size_t)y1 * Win + x1) * ldx);
+        bf16x8_e r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float a = (float)v00[e], bq = (float)v01[e], c = (float)v10[e], d = (float)v11[e];
+            const float top = a + (bq - a) * lx, bot = c + (d - c) * lx;
+            r[e] = (__bf16)(top + (bot - top) * ly);
+        }
+        *reinterpret_cast<bf16x8_e*>(y + (((size_t)b * Hout + oy) * Wout + ox) * ldy + y_coff + c8 * 8) = r;
+    }
+}
+
 hipError_t launch_resize_nhwc(const float* x, int B, int Hin, int Win, int C, int ldx, int x_coff,
                               float* y, int Hout, int Wout, int ldy, int y_coff, hipStream_t s, int bf16) {
     if (C % 4 || ldx % 4 || ldy % 4 || x_coff % 4 || y_coff % 4) return hipErrorInvalidValue;
     const size_t total = (size_t)B * Hout * Wout * (C / 4);
-    if (bf16) hipLaunchKernelGGL(resize_nhwc_kernel<__bf16>, grid1d(total, 256), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x), B, Hin, Win, C / 4,
+    if (bf16 && ((C | ldx | ldy | x_coff | y_coff) & 7) == 0)
+        hipLaunchKernelGGL(resize_nhwc_bf16x8_kernel, grid1d(total / 2, 256), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x), B, Hin, Win, C / 8,
+                           ldx, x_coff, reinterpret_cast<__bf16*>(y), Hout, Wout, ldy, y_coff);
+    else if (bf16) hipLaunchKernelGGL(resize_nhwc_kernel<__bf16>, grid1d(total, 256), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x), B, Hin, Win, C / 4,
                                  ldx, x_coff, reinterpret_cast<__bf16*>(y), Hout, Wout, ldy, y_coff);
     else hipLaunchKernelGGL(resize_nhwc_kernel<float>, grid1d(total, 256), dim3(256), 0, s, x, B, Hin, Win, C / 4, ldx, x_coff,
                             y, Hout, Wout, ldy, y_coff);
@@ -153,33 +186,46 @@ hipError_t launch_nhwc_to_nchw(const float* x, int B, int C, int H, int W, int l
 
 // image2patches 'b c (hg h) (wg w) -> b (c hg wg) h w' (birefnet.rs:288-300), written channels-last:
 // y[b][ty][tx][(c*gh + hg)*gw + wg] = x[b][c][hg*th + ty][wg*tw + tx]; channels [Cimg*gh*gw, cpad) are zeroed.
+// One workgroup = (b, ty, 64 consecutive tx, 64 consecutive output channels): it reads, for each of its channels (c, hg, wg), 64
+// consecutive floats of an image row (coalesced 256-byte segments), turns the [channel][tx] tile through LDS and writes 64-channel
+// vectors per pixel (the one-thread-per-output-element form read 4 bytes per lane from addresses tw or th*W floats apart: 1 TB/s).
+constexpr int I2P_T = 64;
 template <class T>
-__global__ void image2patches_kernel(const float* __restrict__ x, int B, int Cimg, int H, int W, int th, int tw,
-                                     T* __restrict__ y, int ldy, int cpad) {
+__global__ void __launch_bounds__(256) image2patches_kernel(const float* __restrict__ x, int B, int Cimg, int H, int W, int th, int tw,
+                                                            T* __restrict__ y, int ldy, int cpad) {
+    __shared__ float tile[I2P_T][I2P_T + 1];             // [channel][tx]
     const int gh = H / th, gw = W / tw;
     const int cout = Cimg * gh * gw;
-    const size_t total = (size_t)B * th * tw * cpad;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int ch = (int)(idx % cpad);
-        size_t pix = idx / cpad;
-        const int tx = (int)(pix % tw); pix /= tw;
-        const int ty = (int)(pix % th);
-        const int b = (int)(pix / th);
+    const int txb = (tw + I2P_T - 1) / I2P_T, chb = (cpad + I2P_T - 1) / I2P_T;
+    int blk = blockIdx.x;
+    const int ch0 = (blk % chb) * I2P_T; blk /= chb;
+    const int tx0 = (blk % txb) * I2P_T; blk /= txb;
+    const int ty = blk % th;
+    const int b = blk / th;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int i = wv; i < I2P_T; i += 4) {
+        const int ch = ch0 + i, tx = tx0 + lane;
         float v = 0.f;
-        if (ch < cout) {
+        if (ch < cout && tx < tw) {
             const int wg = ch % gw, t = ch / gw;
             const int hg = t % gh, c = t / gh;
             v = x[(((size_t)b * Cimg + c) * H + hg * th + ty) * W + wg * tw + tx];
         }
-        y[(((size_t)b * th + ty) * tw + tx) * ldy + ch] = (T)v;
+        tile[i][lane] = v;
+    }
+    __syncthreads();
+    for (int i = wv; i < I2P_T; i += 4) {                 // pixel tx0 + i, channel ch0 + lane
+        const int tx = tx0 + i, ch = ch0 + lane;
+        if (tx < tw && ch < cpad) y[(((size_t)b * th + ty) * tw + tx) * ldy + ch] = (T)tile[lane][i];
     }
 }
 hipError_t launch_image2patches(const float* x, int B, int Cimg, int H, int W, int th, int tw,
                                 float* y, int ldy, int cpad, hipStream_t s, int bf16) {
     if (H % th || W % tw) return hipErrorInvalidValue;
-    const size_t total = (size_t)B * th * tw * cpad;
-    if (bf16) hipLaunchKernelGGL(image2patches_kernel<__bf16>, grid1d(total, 256), dim3(256), 0, s, x, B, Cimg, H, W, th, tw, reinterpret_cast<__bf16*>(y), ldy, cpad);
-    else hipLaunchKernelGGL(image2patches_kernel<float>, grid1d(total, 256), dim3(256), 0, s, x, B, Cimg, H, W, th, tw, y, ldy, cpad);
+    const size_t blocks = (size_t)B * th * ((tw + I2P_T - 1) / I2P_T) * ((cpad + I2P_T - 1) / I2P_T);
+    if (blocks > 0x7fffffffu) return hipErrorInvalidValue;
+    if (bf16) hipLaunchKernelGGL(image2patches_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, x, B, Cimg, H, W, th, tw, reinterpret_cast<__bf16*>(y), ldy, cpad);
+    else hipLaunchKernelGGL(image2patches_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, x, B, Cimg, H, W, th, tw, y, ldy, cpad);
     return hipGetLastError();
 }
 
