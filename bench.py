@@ -165,12 +165,20 @@ def main(argv=None):
         raise SystemExit("bench.py needs a GPU (the product has no CPU fallback)")
     if compute not in cb.BiRefNet.COMPUTE:
         raise SystemExit(f"compute mode {compute} is not built into this library")
+    # BRN_BENCH_DIST_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks share devices; RCCL refuses
+    # two ranks on one device): same launcher, barriers, max-over-ranks and JSON line; the numbers of such a run mean nothing
+    backend = os.environ.get("BRN_BENCH_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     def barrier():
         if dist is not None:
@@ -195,7 +203,7 @@ def main(argv=None):
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     finite = bool(torch.isfinite(y).all().item())
@@ -326,7 +334,8 @@ def main(argv=None):
         value = images / elapsed
         gflop_ref = GFLOP_PER_IMAGE.get(S)
         workload = (clabel if not custom else f"custom: Swin-L {S}x{S} batch={B}/GPU {compute}") + \
-                   (f"; strong scaling: global batch {B * world} split over {world} rank(s)" if args.strong else "")
+                   (f"; strong scaling: global batch {B * world} split over {world} rank(s)" if args.strong else
+                    (f"; weak scaling: that per-GPU workload on each of {world} ranks, one rank per GPU" if world > 1 else ""))
         out = {
             "metric": "images/sec @1024x1024 Swin-L" if S == 1024 else f"images/sec @{S}x{S} Swin-L",
             "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
