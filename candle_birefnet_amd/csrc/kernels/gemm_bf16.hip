@@ -329,9 +329,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
     bool have = id < id_end;
     if (have) {
         setup(id);
-#pragma unroll
-        for (int s = 0; s < NSTAGE - 1; ++s)
-            if (s < nt) stage(s);
+        if (nt > 0) stage(0);
     }
     bool counted = false;        // the previous item's epilogue issued exactly STORES stores per wave after this item's first loads
     while (have) {
@@ -343,90 +341,111 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
 #pragma unroll
                 for (int r = 0; r < (M16 ? 4 : 16); ++r) acc[i][j][r] = 0.f;
 
-        // One K step.  STAGE_NEXT: the loads of step t + NSTAGE - 1 are part of the step's straight-line block, and the block's
-        // issue order is pinned (sched_group_barrier): left to itself the scheduler issued all LPS LDS-DMA pieces right after the
-        // barrier (60-180 issue cycles each, every wave of the CU at once: the matrix pipe idles meanwhile) and re-used ONE
-        // fragment register set, reading step s+1's fragments only after step s's last MFMA.  Pinned order: the fragments of
-        // k16 step s+1 (second register set) and a share of the LDS-DMA pieces are issued one at a time BETWEEN the MFMAs of step s.
-        auto kstep = [&](int t, auto stage_next) {
-            constexpr bool STAGE_NEXT = decltype(stage_next)::value;
-            // K step t has landed once at most `after` younger steps (and, at t = 0, the previous item's stores) are outstanding
-            const int after = min(nt - 1, t + NSTAGE - 2) - t;
-            constexpr int VM0 = (NSTAGE - 2) * LPS + STORES > 63 ? 63 : (NSTAGE - 2) * LPS + STORES;   // (the counter has 6 bits; a smaller N only waits longer)
-            if (t == 0 && counted && after == NSTAGE - 2) wait_vmcnt<VM0>();
-            else if (NSTAGE >= 4 && after >= 2) wait_vmcnt<2 * LPS>();
-            else if (NSTAGE >= 3 && after >= 1) wait_vmcnt<LPS>();
-            else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();                        // every wave's part of step t is in LDS; slot (t-1) % NSTAGE is free
-            if (abl & 4) { if (STAGE_NEXT) stage(t + NSTAGE - 1); return; }
-            const char* sb = smem + (t % NSTAGE) * STAGE_BYTES;
-            // the fragment offsets are recomputed per K step from an opaque copy of the lane id (a dozen VALU beside 64 MFMAs): kept in
-            // registers across the persistent loop they were the values the allocator chose to spill, and reloaded here every step
+        // ---- K loop.  Two ring slots; the workgroup barrier of a K step sits BEFORE its last sub-step:
+        //   sub-steps 0 .. KSUB-2 of step t : MFMAs, each followed by one fragment read of the next sub-step (second register set);
+        //   mid-step                        : s_waitcnt (step t+1 has landed: its LDS-DMA pieces went out one whole K step ago), s_barrier
+        //                                     — every wave has now READ all its fragments of step t, so slot t % 2 is free;
+        //   last sub-step of step t         : MFMAs from registers, each followed by one fragment read of step t+1's FIRST sub-step
+        //                                     (other slot) and one LDS-DMA piece of step t+2 (into the slot just freed).
+        // So no MFMA ever waits for an LDS read right behind a barrier (the first version read its first fragments after the barrier:
+        // ~300 idle cycles of 2300 per step), and a K step's loads have a full K step to land (they had between a quarter and one).
+        // The issue order of every sub-step is pinned with sched_group_barrier: left to itself the scheduler issued all LDS-DMA
+        // pieces in one burst (60-180 issue cycles each, every wave of the CU at once) and kept ONE fragment register set.  Source
+        // order fixes the order of the LDS traffic (the compiler keeps ds_read / LDS-DMA order: it cannot prove them disjoint).
+        // Fragment offsets are recomputed per K step from an opaque copy of the lane id: live across the persistent loop they were
+        // what the register allocator spilled.
+        static_assert(NSTAGE == 2 && KSUB >= 2 && KSUB % 2 == 0, "two ring slots, an even number of sub-steps per K step");
+        constexpr int NF = FM + FN, NM = FM * FN;                  // fragment reads and MFMAs per sub-step (k16 / k32)
+        static_assert(NM >= LPS && NM >= NF, "a sub-step has fewer MFMAs than LDS operations to place between them");
+        bf16x8 af[2][FM], bf[2][FN];
+        // fragment f of sub-step s from ring slot `sb`: A blocks 0 .. FM-1, W blocks FM .. NF-1
+        auto frag_offsets = [&](int (&foff)[KSUB]) {
             int flane = lane;
             asm volatile("" : "+v"(flane));
             const int frow = flane & (FR - 1), fh = flane / FR;
             const int fswz = (frow / RPB) & SWZ_MASK;
-            int foff[KSUB];
 #pragma unroll
-            for (int s = 0; s < KSUB; ++s) foff[s] = (frow / RPB) * 256 + ((((frow % RPB) * CPR + ((M16 ? 4 : 2) * s + fh)) ^ fswz) << 4);
-            constexpr int NF = FM + FN, NM = FM * FN;              // fragment reads and MFMAs per sub-step (k16 / k32)
-            constexpr int DMA_STEPS = KSUB > 1 ? KSUB - 1 : 1;     // the pieces go out during the first KSUB-1 k16 steps
-            constexpr bool PIN = SCHED && NM >= (LPS + DMA_STEPS - 1) / DMA_STEPS && (BSINGLE || NM >= NF);   // (tiny wave tiles: left to the scheduler)
-            // MFMA order inside a sub-step: W block j outer, A block i inner (m = j FM + i).  The W fragments are single-buffered: the
-            // fragment of block j for sub-step S + 1 is read right after the last MFMA that used it in sub-step S (m = j FM + FM - 1); the
-            // A fragments (all live to the end of the sub-step) are double-buffered and read after the first FM MFMAs.
-            bf16x8 af[2][FM], bf[2][FN];
-            auto read_a = [&](int s, int f) {
-                af[s & 1][f] = *reinterpret_cast<const bf16x8*>(sb + a_base + f * (FR * ROWB) + (foff[s % KSUB] ^ ((f & 1) ? ODD_FLIP : 0)));
-            };
-            auto read_b = [&](int s, int f) {
-                bf[s & 1][f] = *reinterpret_cast<const bf16x8*>(sb + b_base + f * (FR * ROWB) + (foff[s % KSUB] ^ ((f & 1) ? ODD_FLIP : 0)));
-            };
-            if (!PIN && STAGE_NEXT) stage(t + NSTAGE - 1);
-#pragma unroll
-            for (int f = 0; f < FM; ++f) read_a(0, f);
-#pragma unroll
-            for (int f = 0; f < FN; ++f) read_b(0, f);
-            // Source order = issue order of the LDS traffic (the compiler keeps ds_read / LDS-DMA order: it cannot prove them
-            // disjoint); the MFMAs are pinned between them by the sched_group_barrier sequence below.
-            static_for<0, KSUB>([&](auto sc) {
-                constexpr int S = decltype(sc)::value;
-                constexpr int d0 = S < DMA_STEPS ? (LPS * S) / DMA_STEPS : LPS, d1 = S < DMA_STEPS ? (LPS * (S + 1)) / DMA_STEPS : LPS;
+            for (int q = 0; q < KSUB; ++q) foff[q] = (frow / RPB) * 256 + ((((frow % RPB) * CPR + ((M16 ? 4 : 2) * q + fh)) ^ fswz) << 4);
+        };
+        auto read_a = [&](const char* sb, const int (&foff)[KSUB], int sub, int f) {
+            af[sub & 1][f] = *reinterpret_cast<const bf16x8*>(sb + a_base + f * (FR * ROWB) + (foff[sub] ^ ((f & 1) ? ODD_FLIP : 0)));
+        };
+        auto read_b = [&](const char* sb, const int (&foff)[KSUB], int sub, int f) {
+            bf[sub & 1][f] = *reinterpret_cast<const bf16x8*>(sb + b_base + f * (FR * ROWB) + (foff[sub] ^ ((f & 1) ? ODD_FLIP : 0)));
+        };
+        // one sub-step: NM MFMAs on register set S & 1; after MFMA m, in this order: the A fragment m (m < FM) and the W fragment of the
+        // next sub-step (BSINGLE: W block m / FM right after its last use, MFMA order W block outer; else W fragment m - FM), then
+        // LDS-DMA piece m of K step `tstage` (STAGE only)
+        auto substep = [&](auto sc, auto next_c, auto stage_c, const char* sbn, const int (&foff)[KSUB], int nsub, int tstage) {
+            constexpr int S = decltype(sc)::value;
+            constexpr bool NEXT = decltype(next_c)::value, STAGE = decltype(stage_c)::value;
+            static_for<0, NM>([&](auto mc) {
+                constexpr int Mi = decltype(mc)::value;
+                if (NEXT && Mi < FM) read_a(sbn, foff, nsub, Mi);
+                if (NEXT && BSINGLE && Mi % FM == FM - 1) read_b(sbn, foff, nsub, Mi / FM);
+                if (NEXT && !BSINGLE && Mi >= FM && Mi < NF) read_b(sbn, foff, nsub, Mi - FM);
+                if (STAGE && Mi < LPS) stage_piece(tstage, Mi);
+            });
+            static_for<0, NM>([&](auto mc) {                      // transposed product: W fragment first
+                constexpr int Mi = decltype(mc)::value;
+                constexpr int i = BSINGLE ? Mi % FM : Mi / FN, j = BSINGLE ? Mi / FM : Mi % FN;
+                if constexpr (M16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[S & 1][j], af[S & 1][i], acc[i][j], 0, 0, 0);
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[S & 1][j], af[S & 1][i], acc[i][j], 0, 0, 0);
+            });
+            if (STAGE) stage_advance();
+            if (SCHED) {
                 static_for<0, NM>([&](auto mc) {
                     constexpr int Mi = decltype(mc)::value;
-                    if (S + 1 < KSUB && Mi < FM) read_a(S + 1, Mi);
-                    if (BSINGLE && S + 1 < KSUB && Mi % FM == FM - 1) read_b(S + 1, Mi / FM);
-                    if (!BSINGLE && S + 1 < KSUB && Mi >= FM && Mi < NF) read_b(S + 1, Mi - FM);
-                    if (PIN && STAGE_NEXT && Mi < d1 - d0) stage_piece(t + NSTAGE - 1, d0 + Mi);
-                });
-                static_for<0, NM>([&](auto mc) {                  // transposed product: W fragment first
-                    constexpr int Mi = decltype(mc)::value;
-                    constexpr int i = BSINGLE ? Mi % FM : Mi / FN, j = BSINGLE ? Mi / FM : Mi % FN;
-                    if constexpr (M16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[S & 1][j], af[S & 1][i], acc[i][j], 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[S & 1][j], af[S & 1][i], acc[i][j], 0, 0, 0);
-                });
-            });
-            if (PIN && STAGE_NEXT) stage_advance();
-            if (PIN) {
-                __builtin_amdgcn_sched_group_barrier(0x100, NF, 0);  // sub-step 0's fragments
-                static_for<0, KSUB>([&](auto sc) {
-                    constexpr int S = decltype(sc)::value;
-                    constexpr int d0 = S < DMA_STEPS ? (LPS * S) / DMA_STEPS : LPS, d1 = S < DMA_STEPS ? (LPS * (S + 1)) / DMA_STEPS : LPS;
-                    static_for<0, NM>([&](auto mc) {
-                        constexpr int Mi = decltype(mc)::value;
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        if (S + 1 < KSUB && Mi < FM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        if (BSINGLE && S + 1 < KSUB && Mi % FM == FM - 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        if (!BSINGLE && S + 1 < KSUB && Mi >= FM && Mi < NF) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        if (STAGE_NEXT && Mi < d1 - d0) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-                    });
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (NEXT && Mi < FM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (NEXT && BSINGLE && Mi % FM == FM - 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (NEXT && !BSINGLE && Mi >= FM && Mi < NF) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (STAGE && Mi < LPS) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
                 });
             }
         };
-        {
+        // K step t: has_next = step t+1 exists (mid-step barrier + its first fragments), has_next2 = step t+2 exists (its loads go out)
+        auto kstep = [&](int t, auto has_next, auto has_next2) {
+            constexpr bool HN = decltype(has_next)::value, HN2 = decltype(has_next2)::value;
+            const char* sb = smem + (t & 1) * STAGE_BYTES;
+            const char* sbn = smem + ((t + 1) & 1) * STAGE_BYTES;
+            int foff[KSUB];
+            frag_offsets(foff);
+            static_for<0, KSUB - 1>([&](auto sc) {
+                constexpr int S = decltype(sc)::value;
+                substep(sc, std::true_type{}, std::false_type{}, sb, foff, S + 1, 0);
+            });
+            if (HN) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // step t+1 landed (this wave's pieces); this wave's reads of slot t & 1 done
+                __builtin_amdgcn_s_barrier();
+            }
+            substep(std::integral_constant<int, KSUB - 1>{}, has_next, has_next2, sbn, foff, 0, t + 2);
+        };
+        if (abl & 4) {                                                // diag: loads only
+            for (int t = 0; t < nt; ++t) {
+                wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                if (t + 1 < nt) stage(t + 1);
+            }
+        } else if (nt > 0) {
+            // tile prologue: step 0 has landed (at most the previous item's un-waited stores are younger), every wave is out of the previous
+            // item's epilogue (its patches live in slot 1); step 1 goes out, the first fragments come in — the one exposed LDS read per tile
+            constexpr int VM0 = STORES > 63 ? 63 : STORES;           // (the counter has 6 bits; a smaller N only waits longer)
+            if (counted) wait_vmcnt<VM0>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (nt > 1) stage(1);
+            {
+                int foff[KSUB];
+                frag_offsets(foff);
+#pragma unroll
+                for (int f = 0; f < FM; ++f) read_a(smem, foff, 0, f);
+#pragma unroll
+                for (int f = 0; f < FN; ++f) read_b(smem, foff, 0, f);
+            }
             int t = 0;
-            for (; t + NSTAGE - 1 < nt; ++t) kstep(t, std::true_type{});
-            for (; t < nt; ++t) kstep(t, std::false_type{});
+            for (; t + 2 < nt; ++t) kstep(t, std::true_type{}, std::true_type{});
+            if (t + 1 < nt) { kstep(t, std::true_type{}, std::false_type{}); ++t; }
+            kstep(t, std::false_type{}, std::false_type{});
         }
 
         // ---- hand over: the finished item keeps (e_m0, e_n0, e_slice); the staging state moves on to the next item ----
@@ -436,9 +455,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
         __builtin_amdgcn_s_barrier();                            // all fragment reads of the finished item are done: the ring is free
         if (have) {
             setup(id);
-#pragma unroll
-            for (int s = 0; s < NSTAGE - 1; ++s)
-                if (s < nt) stage(s);                            // next item's first K steps: in flight during the epilogue below
+            if (nt > 0) stage(0);                                // next item's first K step: in flight during the epilogue below
         }
         if (abl & 8) { if (acc[0][0][0] == 123.456f) p.C[0] = 1.f; counted = false; continue; }
 
@@ -696,7 +713,7 @@ hipError_t launch_gemm_bf16(const GemmParams& p_in, const GemmPlan& pl, float* w
     if (p_in.wp_ld < (p_in.K + 63) / 64 * 64 || (p_in.wp_ld & 7)) return hipErrorInvalidValue;
     if (p_in.mode == GEMM_CONV_NHWC && ((p_in.Cin & 31) || p_in.Cin < 64 || p_in.K != p_in.kh * p_in.kw * p_in.Cin)) return hipErrorInvalidValue;
     if (p_in.mode != GEMM_DENSE && p_in.mode != GEMM_CONV_NHWC) return hipErrorInvalidValue;
-    const int bn_need = (pl.cfg == 1 || pl.cfg == 15) ? 64 : ((pl.cfg == 2 || pl.cfg == 13) ? 256 : (pl.cfg == 3 ? 192 : 128));
+    const int bn_need = pl.cfg == 1 ? 64 : ((pl.cfg == 2 || pl.cfg == 19) ? 256 : (pl.cfg == 3 ? 192 : 128));
     if (p_in.wp_rows < (p_in.N + bn_need - 1) / bn_need * bn_need) return hipErrorInvalidValue;   // W rows padded to the tile
     GemmParams p = p_in;
     p.splitk = pl.splitk < 1 ? 1 : pl.splitk;
@@ -707,12 +724,8 @@ hipError_t launch_gemm_bf16(const GemmParams& p_in, const GemmPlan& pl, float* w
     else if (pl.cfg == 2) e = launch_bf16_cfg<256, 256, 4, 2, 2, 64, BRN_BF16_CFG2_M16 != 0, BRN_BF16_CFG2_M16 != 0>(p, s);
     else if (pl.cfg == 3) e = launch_bf16_cfg<256, 192, 4, 2, 2, 64>(p, s);
 #ifdef BRN_DIAG_BUILD          // candidates kept for sweeps (tools/gemm_bf16_sweep.py)
-    else if (pl.cfg == 10) e = launch_bf16_cfg<128, 128, 2, 2, 3, 32>(p, s);
-    else if (pl.cfg == 11) e = launch_bf16_cfg<256, 128, 4, 2, 3, 64>(p, s);
     else if (pl.cfg == 12) e = launch_bf16_cfg<256, 128, 4, 2, 2, 64>(p, s);
-    else if (pl.cfg == 13) e = launch_bf16_cfg<256, 256, 4, 2, 3, 32>(p, s);
-    else if (pl.cfg == 14) e = launch_bf16_cfg<128, 128, 2, 2, 4, 32>(p, s);
-    else if (pl.cfg == 15) e = launch_bf16_cfg<256, 64, 4, 2, 3, 64>(p, s);
+    else if (pl.cfg == 19) e = launch_bf16_cfg<256, 256, 2, 2, 2, 64, false, false>(p, s);   // 4 waves of 128 x 128, accumulators in AGPRs
 #endif
     else e = launch_bf16_cfg<128, 128, 2, 2, 2, 64>(p, s);
     if (e != hipSuccess || p.splitk == 1) return e;

@@ -12,8 +12,7 @@ SHAPES = [(40960, 2304, 768), (40960, 768, 768), (40960, 3072, 768), (40960, 768
           (163840, 1152, 384), (163840, 1536, 384), (163840, 384, 1536),                      # stage 1
           (10240, 4608, 1536), (10240, 6144, 1536), (10240, 1536, 6144),                      # stage 3
           (5120, 2304, 768), (5120, 3072, 768), (5120, 768, 3072)]                            # stage 2 at B=1
-CFGS = {0: "128x128", 1: "128x64", 2: "256x256", 3: "256x192", 10: "128x128 k32 s3", 11: "256x128 s3", 12: "256x128 s2", 13: "256x256 k32 s3",
-        14: "128x128 k32 s4", 15: "256x64 s3", -1: "plan"}
+CFGS = {0: "128x128", 1: "128x64", 2: "256x256", 3: "256x192", 12: "256x128", 19: "256x256 4w", -1: "plan"}
 if os.environ.get("BRN_SWEEP_CFGS"):
     CFGS = {int(c): CFGS.get(int(c), str(c)) for c in os.environ["BRN_SWEEP_CFGS"].split(",")}
 if len(sys.argv) > 1:
