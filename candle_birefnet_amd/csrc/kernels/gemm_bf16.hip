@@ -99,6 +99,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
+__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, int soff, void* lds_dst) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+}
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 __device__ __forceinline__ f32x4_b zero4b() { f32x4_b z = {0.f, 0.f, 0.f, 0.f}; return z; }
@@ -179,7 +182,7 @@ __device__ __forceinline__ void store_row8(const GemmParams& p, int m, int n, fl
 // item's C rows are stored, and those stores are not waited for before the next K loop starts (counted vmcnt: loads, stores
 // and LDS-DMA retire in issue order).  Measured before (one workgroup per tile, tools/gemm_bf16_ablate.py, 40960 x 2304 x 768):
 // 49 us of 264 were workgroup launch + prologue, 68 the epilogue, 64 exposed load latency, 83 the MFMA loop itself.
-template <int BM, int BN, int WM, int WN, int NSTAGE, int MODE, int BBK, int EPI, bool M16 = BRN_BF16_MFMA16 != 0, bool BSINGLE = BRN_BF16_BSINGLE != 0>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int MODE, int BBK, int EPI, bool M16 = BRN_BF16_MFMA16 != 0, bool BSINGLE = BRN_BF16_BSINGLE != 0, bool KT = false>
 __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams p) {
     constexpr int NW = WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;   // TM x TN: 32 x 32 blocks of a wave tile (epilogue rounds)
@@ -250,11 +253,23 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
 
     // ---- state of the work item whose K steps are being staged ----
     int m0 = 0, n0 = 0, slice = 0, kt0 = 0, nt = 0;
+    // Dense operands without a K tail (KT = false: K % 64 == 0, every dense GEMM of the model): an LDS-DMA piece's address is a UNIFORM
+    // 64-bit base (tile origin + K step, SGPRs, advanced by scalar adds) + a 32-bit per-lane byte offset fixed for the whole tile
+    // (a_voff / w_voff) — no vector arithmetic per piece (the 64-bit per-lane address + zero-page select of the general form was
+    // ~8 VALU per piece: with the MFMA issue slots it saturated the SIMD's issue).  Rows >= M read row M - 1 instead of zeros: they
+    // only feed accumulator rows that are never stored.  KT = true (K % 64 == 32) and the conv form keep the general address + select.
+    constexpr bool FAST = MODE == GEMM_DENSE && !KT;
     long a_off[LA];        // dense: element offset of (row, k = kch); conv: element offset of image b of the row's pixel (+ a_coff)
+    unsigned a_voff[LA], w_voff[LB];
     int a_iy[LA], a_ix[LA];
     bool a_ok[LA];
     int c_ci = 0, c_ky = 0, c_kx = 0;      // conv: (tap, channel) of this lane's chunk, advanced by BBK channels per K step
     long w_off0 = 0;
+    // FAST: buffer resources based at (row m0, k = kt0 * BBK) of A / (row n0, same k) of W: `buffer_load_dwordx4 v_off, s[rsrc], s_koff offen lds`
+    __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Ab), 0, 0x7fffffff, 0x00020000);
+    __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Wb), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < LB; ++j) w_voff[j] = (unsigned)(((lrow + RPI * NW * j) * p.wp_ld + kch) * 2);
     auto setup = [&](int work) {
         slice = work / ntiles;
         const int tile = work - slice * ntiles;
@@ -269,8 +284,10 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
             const int m = m0 + lrow + RPI * NW * j;
             a_ok[j] = m < p.M;
             a_iy[j] = 0; a_ix[j] = 0;
+            a_voff[j] = 0;
             if (MODE == GEMM_DENSE) {
                 a_off[j] = (long)m * p.lda + p.a_coff + kch;
+                a_voff[j] = (unsigned)(((min(m, p.M - 1) - m0) * p.lda + kch) * 2);
             } else {
                 const int hw = p.Hout * p.Wout;
                 const int b = m / hw, rem = m - b * hw;
@@ -288,12 +305,20 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
         }
         // W rows n0 + lrow + RPI NW j of the padded [rows][wp_ld] bf16 matrix (rows and K zero-padded to the tile: always in bounds)
         w_off0 = (long)(n0 + lrow) * p.wp_ld + kch;
+        if (FAST) {
+            a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Ab + (long)m0 * p.lda + p.a_coff + (long)kt0 * BBK), 0, 0x7fffffff, 0x00020000);
+            w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Wb + (long)n0 * p.wp_ld + (long)kt0 * BBK), 0, 0x7fffffff, 0x00020000);
+        }
     };
     // piece j of K step t (local index) into ring slot t % NSTAGE: j < LA = A rows, else W rows; stage_advance() after the last piece
     auto stage_piece = [&](int t, int j) {
         char* sbase = smem + (t % NSTAGE) * STAGE_BYTES + wave * 1024;
         const int kbase = (kt0 + t) * BBK;
-        if (j < LA) {
+        if (FAST) {
+            const int koff = t * (BBK * 2);                      // uniform: the instruction's SGPR offset
+            if (j < LA) { if (!(abl & 1)) blds16(a_rsrc, a_voff[j], koff, sbase + j * (NW * 1024)); }
+            else if (!(abl & 2)) blds16(w_rsrc, w_voff[j - LA], koff, sbase + A_BYTES + (j - LA) * (NW * 1024));
+        } else if (j < LA) {
             if (MODE == GEMM_DENSE) {
                 const bool kin = kbase + kch < p.K;              // K tail (K % 64 == 32): the upper chunks read zeros
                 const char* src = (a_ok[j] && kin) ? reinterpret_cast<const char*>(Ab + a_off[j] + kbase) : zero;
@@ -648,7 +673,7 @@ __global__ void splitk_reduce_bf16_kernel(const GemmParams p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, int BBK, bool M16 = BRN_BF16_MFMA16 != 0, bool BSINGLE = BRN_BF16_BSINGLE != 0>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int BBK, bool M16 = BRN_BF16_MFMA16 != 0, bool BSINGLE = BRN_BF16_BSINGLE != 0, bool KT = false>
 static hipError_t launch_bf16_cfg(const GemmParams& p, hipStream_t s) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.splitk;
     // persistent workgroups: as many as fit the chip at once (LDS-limited: NSTAGE ring slots each), never more than work items
@@ -661,7 +686,7 @@ static hipError_t launch_bf16_cfg(const GemmParams& p, hipStream_t s) {
     const bool plain = p.splitk == 1 && (p.N & 7) == 0;
     if (plain && !p.c_f32 && ((p.ldc | p.c_coff) & 7) == 0 && (!p.R || (!p.r_f32 && ((p.ldr | p.r_coff) & 7) == 0))) epi = 0;
     else if (plain && !p.bbias && p.c_f32 && ((p.ldc | p.c_coff) & 3) == 0 && (!p.R || (p.r_f32 && ((p.ldr | p.r_coff) & 3) == 0))) epi = 1;
-#define BRN_BF16_LAUNCH(MODE_, EPI_) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, NSTAGE, MODE_, BBK, EPI_, M16, BSINGLE>), grid, block, 0, s, p)
+#define BRN_BF16_LAUNCH(MODE_, EPI_) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, NSTAGE, MODE_, BBK, EPI_, M16, BSINGLE, KT && MODE_ == GEMM_DENSE>), grid, block, 0, s, p)
     if (p.mode == GEMM_DENSE) {
         if (epi == 0) BRN_BF16_LAUNCH(GEMM_DENSE, 0); else if (epi == 1) BRN_BF16_LAUNCH(GEMM_DENSE, 1); else BRN_BF16_LAUNCH(GEMM_DENSE, 2);
     } else if (p.mode == GEMM_CONV_NHWC) {
@@ -677,10 +702,10 @@ static hipError_t launch_bf16_cfg(const GemmParams& p, hipStream_t s) {
 // 64, 2 ring slots, persistent workgroups:
 //   cfg 0: 128x128, 4 waves (64 KB: 2 workgroups / CU)       cfg 1: 128x64, 4 waves (48 KB: 3 / CU)
 //   cfg 2: 256x256, 8 waves (128 KB: 1 / CU), 32x32x16       cfg 3: 256x192, 8 waves (112 KB: 1 / CU)
-// eff = measured throughput of a full-chip launch relative to cfg 2 (same box, round 2: 16x16x32 lifted cfg 0 / 1 / 3 by 5-13 %);
-// cfg 3 loses to cfg 2 on long K (its intake per flop is 17 % higher), wins on short K and wherever it divides N or the grid better.
+// eff = measured throughput of a full-chip launch relative to cfg 2 (same box, end of round 2: after the buffer-addressed LDS-DMA
+// and the mid-step barrier, which helped the 8-wave 256 x 256 tile most); cfg 3 wins where it divides N or the grid better.
 struct Bf16Cfg { int cfg, bm, bn, slots; double eff, eff_long_k; };
-static const Bf16Cfg kBf16Cfgs[] = {{0, 128, 128, 512, 0.92, 0.88}, {1, 128, 64, 768, 0.76, 0.74}, {2, 256, 256, 256, 1.00, 1.00}, {3, 256, 192, 256, 1.00, 0.90}};
+static const Bf16Cfg kBf16Cfgs[] = {{0, 128, 128, 512, 0.86, 0.80}, {1, 128, 64, 768, 0.72, 0.68}, {2, 256, 256, 256, 1.00, 1.00}, {3, 256, 192, 256, 0.93, 0.85}};
 GemmPlan plan_gemm_bf16(int M, int N, int K, bool f32_residual, bool gelu) {
     GemmPlan pl{0, 1, 0};
     double best = 1e300;
@@ -720,7 +745,9 @@ hipError_t launch_gemm_bf16(const GemmParams& p_in, const GemmPlan& pl, float* w
     p.part = ws;
     if (p.splitk > 1 && !ws) return hipErrorInvalidValue;
     hipError_t e;
-    if (pl.cfg == 1) e = launch_bf16_cfg<128, 64, 2, 2, 2, 64>(p, s);
+    // a dense K tail (K % 64 == 32: none in the model, reachable through the op-level entry points) runs on the 128 x 128 tile's general-address form
+    if (p.mode == GEMM_DENSE && (p.K & 63)) e = launch_bf16_cfg<128, 128, 2, 2, 2, 64, BRN_BF16_MFMA16 != 0, BRN_BF16_BSINGLE != 0, true>(p, s);
+    else if (pl.cfg == 1) e = launch_bf16_cfg<128, 64, 2, 2, 2, 64>(p, s);
     else if (pl.cfg == 2) e = launch_bf16_cfg<256, 256, 4, 2, 2, 64, BRN_BF16_CFG2_M16 != 0, BRN_BF16_CFG2_M16 != 0>(p, s);
     else if (pl.cfg == 3) e = launch_bf16_cfg<256, 192, 4, 2, 2, 64>(p, s);
 #ifdef BRN_DIAG_BUILD          // candidates kept for sweeps (tools/gemm_bf16_sweep.py)
