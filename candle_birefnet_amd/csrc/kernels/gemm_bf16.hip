@@ -261,6 +261,8 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
     constexpr bool FAST = MODE == GEMM_DENSE && !KT;
     long a_off[LA];        // dense: element offset of (row, k = kch); conv: element offset of image b of the row's pixel (+ a_coff)
     unsigned a_voff[LA], w_voff[LB];
+    int a_pix[LA];         // conv: byte offset of (image - first image of the tile, iy0, ix0, channel 0) from the tile's buffer base (may be negative in the padding)
+    int tap_off = 0;       // conv: byte offset of this lane's (tap, channel) inside a pixel neighbourhood: ((ky dil) Win + kx dil) lda 2 + 2 ci
     int a_iy[LA], a_ix[LA];
     bool a_ok[LA];
     int c_ci = 0, c_ky = 0, c_kx = 0;      // conv: (tap, channel) of this lane's chunk, advanced by BBK channels per K step
@@ -295,6 +297,8 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
                 a_iy[j] = oy * p.stride - p.pad;
                 a_ix[j] = ox * p.stride - p.pad;
                 a_off[j] = (long)b * p.Hin * p.Win * p.lda + p.a_coff;
+                const int b0 = min(m0, p.M - 1) / hw;            // first image of the tile: the buffer base (a tile spans at most two images' worth of offsets)
+                a_pix[j] = (((a_ok[j] ? b - b0 : 0) * p.Hin + a_iy[j]) * p.Win + a_ix[j]) * p.lda * 2;
             }
         }
         if (MODE == GEMM_CONV_NHWC) {
@@ -302,6 +306,10 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
             const int tap = k / p.Cin;
             c_ci = k - tap * p.Cin;
             c_ky = tap / p.kw; c_kx = tap - c_ky * p.kw;
+            tap_off = ((c_ky * p.dil) * p.Win + c_kx * p.dil) * p.lda * 2 + c_ci * 2;
+            const int b0 = min(m0, p.M - 1) / (p.Hout * p.Wout);
+            a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Ab + (long)b0 * p.Hin * p.Win * p.lda + p.a_coff), 0, 0x7fffffff, 0x00020000);
+            w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Wb + (long)n0 * p.wp_ld + (long)kt0 * BBK), 0, 0x7fffffff, 0x00020000);
         }
         // W rows n0 + lrow + RPI NW j of the padded [rows][wp_ld] bf16 matrix (rows and K zero-padded to the tile: always in bounds)
         w_off0 = (long)(n0 + lrow) * p.wp_ld + kch;
@@ -324,21 +332,30 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
                 const char* src = (a_ok[j] && kin) ? reinterpret_cast<const char*>(Ab + a_off[j] + kbase) : zero;
                 if (!(abl & 1)) glds16(src, sbase + j * (NW * 1024));
             } else {
-                const bool kin = c_ky < p.kh;                    // beyond the last tap: K tail
+                // implicit GEMM: buffer-addressed too — the lane's pixel offset is fixed for the tile, its (tap, channel) offset is kept
+                // incrementally, and a tap outside the image (or beyond the last tap: K tail) gets an offset past num_records, which
+                // the buffer unit answers with zeros (no zero page, no 64-bit address arithmetic)
+                const bool kin = c_ky < p.kh;
                 const int iy = a_iy[j] + c_ky * p.dil, ix = a_ix[j] + c_kx * p.dil;
                 const bool ok = a_ok[j] && kin && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-                const char* src = ok ? reinterpret_cast<const char*>(Ab + a_off[j] + ((long)iy * p.Win + ix) * p.lda + c_ci) : zero;
-                if (!(abl & 1)) glds16(src, sbase + j * (NW * 1024));
+                const unsigned voff = ok ? (unsigned)(a_pix[j] + tap_off) : 0x80000000u;
+                if (!(abl & 1)) blds16(a_rsrc, voff, 0, sbase + j * (NW * 1024));
             }
         } else {
             const int jw = j - LA;
-            if (!(abl & 2)) glds16(Wb + w_off0 + (long)(RPI * NW * jw) * p.wp_ld + kbase, sbase + A_BYTES + jw * (NW * 1024));
+            if (MODE == GEMM_CONV_NHWC) { if (!(abl & 2)) blds16(w_rsrc, w_voff[jw], t * (BBK * 2), sbase + A_BYTES + jw * (NW * 1024)); }
+            else if (!(abl & 2)) glds16(Wb + w_off0 + (long)(RPI * NW * jw) * p.wp_ld + kbase, sbase + A_BYTES + jw * (NW * 1024));
         }
     };
     auto stage_advance = [&]() {
         if (MODE == GEMM_CONV_NHWC) {
             c_ci += BBK;
-            if (c_ci >= p.Cin) { c_ci -= p.Cin; if (++c_kx == p.kw) { c_kx = 0; ++c_ky; } }
+            tap_off += BBK * 2;
+            if (c_ci >= p.Cin) {
+                c_ci -= p.Cin;
+                if (++c_kx == p.kw) { c_kx = 0; ++c_ky; }
+                tap_off = ((c_ky * p.dil) * p.Win + c_kx * p.dil) * p.lda * 2 + c_ci * 2;
+            }
         }
     };
     auto stage = [&](int t) {                                   // all pieces of K step t at once (prologue of a work item)
@@ -738,6 +755,7 @@ hipError_t launch_gemm_bf16(const GemmParams& p_in, const GemmPlan& pl, float* w
     if (p_in.wp_ld < (p_in.K + 63) / 64 * 64 || (p_in.wp_ld & 7)) return hipErrorInvalidValue;
     if (p_in.mode == GEMM_CONV_NHWC && ((p_in.Cin & 31) || p_in.Cin < 64 || p_in.K != p_in.kh * p_in.kw * p_in.Cin)) return hipErrorInvalidValue;
     if (p_in.mode != GEMM_DENSE && p_in.mode != GEMM_CONV_NHWC) return hipErrorInvalidValue;
+    if (p_in.mode == GEMM_CONV_NHWC && (double)p_in.Hin * p_in.Win * p_in.lda * 2.0 >= 1073741824.0) return hipErrorInvalidValue;   // 32-bit buffer offsets span two images
     const int bn_need = pl.cfg == 1 ? 64 : ((pl.cfg == 2 || pl.cfg == 19) ? 256 : (pl.cfg == 3 ? 192 : 128));
     if (p_in.wp_rows < (p_in.N + bn_need - 1) / bn_need * bn_need) return hipErrorInvalidValue;   // W rows padded to the tile
     GemmParams p = p_in;
