@@ -5,17 +5,19 @@
 // residual / concat-slice write).
 //
 // Structure (all waves load AND multiply; no register staging at all):
-//   * operands go HBM/L2 -> LDS directly (global_load_lds_dwordx4: 16 B per lane, 1 KiB per wave instruction), K step 64
-//     (128-byte tile rows), NSTAGE-deep LDS ring, ONE raw s_barrier per K step, counted s_waitcnt vmcnt(N): the tiles of
-//     the next NSTAGE-2 K steps stay in flight across the barrier (cdna_hip_programming.md, "Pipelining across barriers");
+//   * operands go HBM/L2 -> LDS directly (LDS-DMA, 16 B per lane, 1 KiB per wave instruction), K step 64 (128-byte tile rows), two
+//     ring slots, ONE raw s_barrier per K step placed before the step's last sub-step, so that the next step's first fragments
+//     and the step-after-next's loads ride on MFMAs (see the K loop);
+//   * dense operands and the implicit-GEMM form are buffer-addressed (`buffer_load_dwordx4 v_off, s[rsrc], s_koff offen lds`):
+//     a resource per tile, a 32-bit lane offset fixed for the tile, the K advance in an SGPR — no vector arithmetic per piece;
+//     conv taps outside the image get an offset past num_records (the buffer unit answers with zeros); only a dense K tail
+//     (K % 64 == 32) keeps 64-bit per-lane addresses with a select on the ADDRESS (zero page), never on the data;
 //   * LDS image of a tile: rows 2p, 2p+1 share one 256-byte bank row, whose sixteen 16-byte slots are XOR-permuted by
 //     (p & 15): slot(r, c) = ((r & 1) << 3 | c) ^ ((r >> 1) & 15).  A ds_read_b128 lane group (16 lanes = 16 different rows,
-//     same logical chunk c) then touches 16 different slots: conflict-free.  global_load_lds writes lane-linear, so the
-//     permutation is applied to the per-lane SOURCE address (which row / chunk a lane fetches), never to the destination;
+//     same logical chunk c) then touches 16 different slots: conflict-free.  LDS-DMA writes lane-linear, so the
+//     permutation is applied to the per-lane SOURCE offset (which row / chunk a lane fetches), never to the destination;
 //   * a wave's instructions are i = w + NW j, so a lane's (row parity, chunk) is the same for all of them: the implicit-GEMM
-//     modes compute ONE (tap, channel) per lane per K step, by increments (no division in the loop);
-//   * masked elements (conv zero padding, rows >= M, the K tail) are fetched from a 16-byte zero page: a select on the
-//     ADDRESS, never on the data.
+//     mode tracks ONE (tap, channel) per lane per K step, by increments (no division in the loop).
 #include "../brn_kernels.h"
 #include "split_planes.h"
 #include <type_traits>
