@@ -851,7 +851,7 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa][i], bf[pb][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[pb][j], af[pa][i], acc[i][j], 0, 0, 0);   // transposed product: see the C tile image below
             }
     };
     bf16x8 fa0[NP][TM], fb0[NP][TN], fa1[NP][TM], fb1[NP][TN];
@@ -880,14 +880,19 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
     // row-major image of the C tile
     float* ctile = reinterpret_cast<float*>(smem_raw);
     {
-        const int col = lane & 31, rhalf = (lane >> 5) * 4;      // C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        // the product was formed transposed (W fragment = the MFMA's first operand): a lane holds ONE row (lane & 31) of a 32 x 32 block and
+        // columns 8g + 4h + {0..3} in registers 4g .. 4g+3 (h = lane >> 5) — 16 ds_write_b128 per lane instead of 64 ds_write_b32
+        // (rows are 528 bytes apart: 8 consecutive lanes hit 8 x 4 different banks)
+        const int row = lane & 31, h4 = (lane >> 5) * 4;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    ctile[(wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf) * EP_LD + wn * WTN + j * 32 + col] = acc[i][j][r];
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(ctile + (wm * WTM + i * 32 + row) * EP_LD + wn * WTN + j * 32 + 8 * g + h4) = v;
+                }
     }
     }   // consumers
     // ---- epilogue, all eight waves: the producers have nothing left to do, and a 4-wave epilogue was 5-11 us of store-issue
