@@ -723,11 +723,40 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
         static_assert(!APL || KS == 32, "P-layout input is staged in whole 32-deep K tiles");
         const long wrow_stride = (long)p.K * NP;         // W planes interleaved per K tile: [row][K/32][plane][32] bf16
         const __bf16* wsrc = reinterpret_cast<const __bf16*>(p.Wp) + (long)(n0 + wrow) * wrow_stride + wc * 8;
+        // Dense operands are buffer-addressed: a resource per tile (A: based at row m0, num_records = the tile's valid rows, so rows
+        // >= M come back as zeros without a mask; W planes: based at row n0), a 32-bit lane offset fixed for the tile, the K tile in the
+        // instruction's SGPR offset.  The producers share their SIMDs with the MFMA waves: the 64-bit per-lane address arithmetic and
+        // the row mask were ~5 VALU per load, a quarter of the producers' vector work per K tile.
+        constexpr bool BUFA = MODE == GEMM_DENSE && !APL;
+        typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+        __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A + (long)m0 * p.lda), 0,
+                                                                          (int)min((long)(p.M - m0) * p.lda * 4, 0x7fffffffL), 0x00020000);
+        __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(reinterpret_cast<const __bf16*>(p.Wp) + (long)n0 * wrow_stride), 0,
+                                                                          0x7fffffff, 0x00020000);
+        unsigned voff_a[PA], voff_w[PB];
+#pragma unroll
+        for (int i = 0; i < PA; ++i) voff_a[i] = (unsigned)(((lrow + i * RPP) * p.lda + kq * 4) * 4);
+#pragma unroll
+        for (int i = 0; i < PB; ++i) voff_w[i] = (unsigned)(((long)(wrow + i * WRPP) * wrow_stride + wc * 8) * 2);
         f32x4 ra[2][PA];
         bf16x8 rb[2][NP][PB];
         unsigned am[2][PA];
         auto gload = [&](int t, f32x4 (&qa)[PA], bf16x8 (&qb)[NP][PB], unsigned (&qm)[PA]) {
             const int k0 = (kt0 + t) * KS;
+            if (BUFA) {
+                const int wk = (KS == 32 ? (kt0 + t) * (NP * 32) : ((kt0 + t) >> 1) * (NP * 32) + ((kt0 + t) & 1) * 16) * 2;   // bytes, uniform
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                    for (int i = 0; i < PB; ++i)
+                        qb[pl][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, voff_w[i], wk + pl * 64, 0));
+#pragma unroll
+                for (int i = 0; i < PA; ++i) {
+                    qa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff_a[i], k0 * 4, 0));
+                    qm[i] = 0xffffffffu;
+                }
+                return;
+            }
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
@@ -775,7 +804,7 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
 #pragma unroll
             for (int i = 0; i < PA; ++i) {
                 bf16x4 sp[NP];
-                split4<NP>(qa[i], qm[i], sp);
+                if (BUFA) split4<NP, false>(qa[i], qm[i], sp); else split4<NP>(qa[i], qm[i], sp);
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl)
                     *reinterpret_cast<bf16x4*>(As + (pl * BM + lrow + i * RPP) * SLD + kq * 4) = sp[pl];

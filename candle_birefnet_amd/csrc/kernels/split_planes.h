@@ -17,12 +17,12 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float valu_and(float a, unsigned keep) { float r; asm("v_and_b32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(keep)); return r; }
 __device__ __forceinline__ float valu_sub(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ unsigned valu_cvt_pk_bf16(float a, float b) { unsigned r; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-template <int NP>
+template <int NP, bool MASKED = true>   // MASKED = false: the caller's rows are all valid (or were zero-filled by the load): no AND
 __device__ __forceinline__ void split4(const f32x4_sp v, const unsigned keep, bf16x4 (&out)[NP]) {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     float r[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) r[e] = valu_and(v[e], keep);
+    for (int e = 0; e < 4; ++e) r[e] = MASKED ? valu_and(v[e], keep) : v[e];
 #pragma unroll
     for (int pl = 0; pl < NP; ++pl) {
         u32x2 h;
@@ -47,7 +47,7 @@ __device__ __forceinline__ void split4(const f32x4_sp v, const unsigned keep, bf
 template <int NP>
 __device__ __forceinline__ void store_planes(float* row, int col, const f32x4_sp v) {
     bf16x4 sp[NP];
-    split4<NP>(v, 0xffffffffu, sp);
+    split4<NP, false>(v, 0xffffffffu, sp);
     char* base = reinterpret_cast<char*>(row) + (col >> 5) * (64 * NP) + (col & 31) * 2;
 #pragma unroll
     for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<bf16x4*>(base + 64 * pl) = sp[pl];
