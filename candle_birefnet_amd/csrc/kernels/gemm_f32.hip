@@ -727,15 +727,37 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
         // >= M come back as zeros without a mask; W planes: based at row n0), a 32-bit lane offset fixed for the tile, the K tile in the
         // instruction's SGPR offset.  The producers share their SIMDs with the MFMA waves: the 64-bit per-lane address arithmetic and
         // the row mask were ~5 VALU per load, a quarter of the producers' vector work per K tile.
-        constexpr bool BUFA = MODE == GEMM_DENSE && !APL;
+        // The implicit-GEMM form: the resource is based at the first image of the tile, a lane's pixel offset is fixed for the tile, the
+        // K tile's (tap, channel) offset is uniform (Cin % KS == 0: a K tile lies inside one tap) and is added to it; a tap outside the
+        // image gets an offset past num_records, which the buffer unit answers with zeros.  The P-layout form (APL) is the dense one
+        // with 16 NP floats per K tile.
+        constexpr bool BUFA = MODE == GEMM_DENSE;                       // dense (plain or P-layout rows): valid-row num_records, no mask
+        constexpr bool BUFC = MODE == GEMM_CONV_NHWC;
         typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
-        __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A + (long)m0 * p.lda), 0,
-                                                                          (int)min((long)(p.M - m0) * p.lda * 4, 0x7fffffffL), 0x00020000);
+        const int conv_b0 = BUFC ? min(m0, p.M - 1) / (p.Hout * p.Wout) : 0;
+        // (32-bit byte offsets span the two images a tile can touch: larger maps keep the general 64-bit addresses below)
+        const bool bufc_ok = BUFC && (double)p.Hin * p.Win * p.lda * 8.0 < 2147483648.0;
+        __amdgpu_buffer_rsrc_t rsrc_a = BUFC
+            ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A + (long)conv_b0 * p.Hin * p.Win * p.lda + p.a_coff), 0, 0x7fffffff, 0x00020000)
+            : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A + (long)m0 * p.lda), 0, (int)min((long)(p.M - m0) * p.lda * 4, 0x7fffffffL), 0x00020000);
+        int conv_pix[PA];
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            conv_pix[i] = 0;
+            if (BUFC) {
+                const int m = m0 + lrow + i * RPP, hw = p.Hout * p.Wout;
+                const int bq = a_ok[i] ? m / hw - conv_b0 : 0;
+                conv_pix[i] = (((bq * p.Hin + a_iy[i]) * p.Win + a_ix[i]) * p.lda + kq * 4) * 4;   // bytes; negative inside the padding
+            }
+        }
         __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(reinterpret_cast<const __bf16*>(p.Wp) + (long)n0 * wrow_stride), 0,
                                                                           0x7fffffff, 0x00020000);
         unsigned voff_a[PA], voff_w[PB];
 #pragma unroll
-        for (int i = 0; i < PA; ++i) voff_a[i] = (unsigned)(((lrow + i * RPP) * p.lda + kq * 4) * 4);
+        for (int i = 0; i < PA; ++i) {
+            if (APL) { const int q = i * 256 + pt, row = q / (4 * NP), c = q - row * (4 * NP); voff_a[i] = (unsigned)((row * p.lda + c * 4) * 4); }
+            else voff_a[i] = (unsigned)(((lrow + i * RPP) * p.lda + kq * 4) * 4);
+        }
 #pragma unroll
         for (int i = 0; i < PB; ++i) voff_w[i] = (unsigned)(((long)(wrow + i * WRPP) * wrow_stride + wc * 8) * 2);
         f32x4 ra[2][PA];
@@ -752,7 +774,27 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
                         qb[pl][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, voff_w[i], wk + pl * 64, 0));
 #pragma unroll
                 for (int i = 0; i < PA; ++i) {
-                    qa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff_a[i], k0 * 4, 0));
+                    qa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff_a[i], APL ? (kt0 + t) * (64 * NP) : k0 * 4, 0));
+                    qm[i] = 0xffffffffu;
+                }
+                return;
+            }
+            if (BUFC && bufc_ok) {
+                const int wk = (KS == 32 ? (kt0 + t) * (NP * 32) : ((kt0 + t) >> 1) * (NP * 32) + ((kt0 + t) & 1) * 16) * 2;   // bytes, uniform
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                    for (int i = 0; i < PB; ++i)
+                        qb[pl][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, voff_w[i], wk + pl * 64, 0));
+                const int tap = k0 / p.Cin, ci0 = k0 - tap * p.Cin;
+                const int ky = tap / p.kw, kx = tap - ky * p.kw;
+                const int dy = ky * p.dil, dx = kx * p.dil;
+                const int tap_off = ((dy * p.Win + dx) * p.lda + ci0) * 4;        // uniform
+#pragma unroll
+                for (int i = 0; i < PA; ++i) {
+                    const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
+                    const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+                    qa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, ok ? (unsigned)(conv_pix[i] + tap_off) : 0x80000000u, 0, 0));
                     qm[i] = 0xffffffffu;
                 }
                 return;
@@ -804,7 +846,7 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
 #pragma unroll
             for (int i = 0; i < PA; ++i) {
                 bf16x4 sp[NP];
-                if (BUFA) split4<NP, false>(qa[i], qm[i], sp); else split4<NP>(qa[i], qm[i], sp);
+                if (BUFA || (BUFC && bufc_ok)) split4<NP, false>(qa[i], qm[i], sp); else split4<NP>(qa[i], qm[i], sp);
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl)
                     *reinterpret_cast<bf16x4*>(As + (pl * BM + lrow + i * RPP) * SLD + kq * 4) = sp[pl];
