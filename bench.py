@@ -16,6 +16,11 @@ images.  N>1: either launched by torch.distributed.run (RANK / LOCAL_RANK / WORL
 WORLD_SIZE is unset — this process starts the N ranks itself BEFORE anything touches HIP and relays rank 0's JSON line.
 torch.distributed (RCCL) is used for the timing barrier and the max-over-ranks reduction only.
 
+The default line (config c2, no overrides) also carries `other_configs`: at N=1 the bf16 configurations c3 and c5 in both
+deform modes (`c3`, `c3_deformable`, `c5`, `c5_deformable`: own model, warm-up, timed steps bracketed by synchronize, roofline
+block, error of image 0 against the committed strided golden); at N>1 a `c4` / `c4_deformable` block (8 images per GPU bf16 on every
+rank, per-rank times + max).  SURVEY.md D1 assigns the deformable mode to configs 3-5 (the only mode with a gather).
+
 Rank 0 prints ONE JSON line; see DESIGN.md §measurement for how each field is obtained.
 """
 import argparse
@@ -43,6 +48,9 @@ MODES = {
     "bf16": (1, "bf16 (activations and weights stored bf16 in HBM, bf16 MFMA, f32 accumulate / LayerNorm / softmax statistics)", 2),
 }
 GEMM_FAMILIES = ("gemm_dense", "gemm_conv_nhwc", "gemm_gather_nchw", "gemm_deform_nhwc")
+HBM_PEAK_TBS = 8.0                     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 measured with a float4 copy)
+PROFILE_ROUND = ("r03", "r02")         # committed rocprofv3 evidence, newest first (profiles/README.md)
+OTHER_STEPS, OTHER_WARMUP = 10, 3      # timed steps / warm-up of each `other_configs` block
 # BASELINE.json configs[1..4]: (images per GPU, side, compute mode, label)
 CONFIGS = {
     "c2": (1, 1024, "f32_split3", "BASELINE configs[1]: Swin-L 1024x1024 batch=1 fp32 on 1xMI355X (single-image latency)"),
@@ -101,6 +109,8 @@ def parse_args(argv=None):
     ap.add_argument("--also", default=None, help="comma list of other compute modes to time briefly on rank 0 at N=1 ('' = none; default: f32_split2,f32 for c2)")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra steps with per-launch HIP events for the roofline block")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off", "on"])
+    ap.add_argument("--other-configs", default="auto", choices=["auto", "off", "on"],
+                    help="time the other BASELINE configurations in the same run (auto: with the default c2 line)")
     ap.add_argument("--cpu-baseline-size", type=int, default=0, help="image side for the CPU sample (0 = the workload's side, capped at 1024)")
     ap.add_argument("--cpu-torch-worker", type=int, default=0, help=argparse.SUPPRESS)
     return ap.parse_args(argv)
@@ -131,6 +141,92 @@ def launch_ranks(n, cmd, extra_env=None, timeout=None):
     return rc
 
 
+def golden_error(y, S, deform_mode):
+    """max |y[0] - golden| on the committed strided golden of image 0 (seed 1000) for this geometry and deform mode
+    (tests/golden/make_golden.py: fp64 torch restatement at 1024^2, fp32 at 2048^2), or None when there is none"""
+    import numpy as np
+    tag = "ref" if deform_mode == "reference_cpu" else "def"
+    path = os.path.join(ROOT, "tests", "golden", f"model_{S}{'' if tag == 'ref' else '_def'}.npz")
+    stride = {1024: 16, 2048: 32}.get(S)
+    key = f"m{S}_full_{tag}_s{stride}"
+    if stride is None or not os.path.exists(path):
+        return None
+    k = np.load(path)
+    if key not in k.files:
+        return None
+    yn = y[0:1, :, ::stride, ::stride].float().cpu().numpy().astype(np.float64)
+    return float(np.abs(yn - k[key].astype(np.float64)).max())
+
+
+def profile_model(model, x, n):
+    """n profiled forwards (HIP events bracketing every launch on the launch stream): per-family sums + the stage timers"""
+    fam = {}
+    stage_ms = None
+    model.set_profiling(True)
+    for _ in range(n):
+        model.forward_logits(x)
+        for k, v in model.last_kernel_stats().items():
+            a = fam.setdefault(k, {"launches": 0, "ms": 0.0, "gflop": 0.0, "gbytes": 0.0})
+            a["launches"] += v["launches"]; a["ms"] += v["ms"]; a["gflop"] += v["flop"] / 1e9; a["gbytes"] += v["bytes"] / 1e9
+        stage_ms = model.last_timings()
+    model.set_profiling(False)
+    return fam, stage_ms
+
+
+def roofline_block(fam, n, compute, traffic_key, quote_traffic):
+    """roofline of the dominant kernel family (the GEMM kernels) from `n` profiled steps; `traffic` = HBM-side bytes per launch from
+    the committed rocprofv3 --pmc profile of the same configuration (profiles/<round>_gemm_traffic_<traffic_key>.json)"""
+    fl = sum(fam[k]["gflop"] for k in GEMM_FAMILIES) * 1e9
+    ms = sum(fam[k]["ms"] for k in GEMM_FAMILIES)
+    by = sum(fam[k]["gbytes"] for k in GEMM_FAMILIES) * 1e9
+    launches = sum(fam[k]["launches"] for k in GEMM_FAMILIES)
+    achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    npairs = MODES[compute][0]
+    peak = PEAK_F32_MFMA_TFLOPS if npairs == 0 else PEAK_BF16_MFMA_TFLOPS / npairs
+    traffic, traffic_note = None, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE not collected for this configuration"
+    if quote_traffic:
+        for rnd in PROFILE_ROUND:
+            tj = os.path.join(ROOT, "profiles", f"{rnd}_gemm_traffic_{traffic_key}.json")
+            if os.path.exists(tj):
+                t = json.load(open(tj))
+                traffic = round((t["hbm_read_gb_x2corrected"] + t["hbm_write_gb"]) * 1e9 / t["gemm_family_dispatches"])
+                traffic_note = (f"bytes per launch, gemm family average, from {os.path.relpath(tj, ROOT)} (rocprofv3 --pmc FETCH_SIZE x2 "
+                                "gfx950 correction + WRITE_SIZE, separate passes); algorithmic bytes per launch = "
+                                f"{round(by / n / max(1, launches // n))}")
+                break
+    roof = {
+        "bound": "mfma",
+        "kernel": {"f32": "gemm family: gemm_f32_kernel", "bf16": "gemm family: gemm_bf16_kernel (+ gemm_f32_kernel for the NCHW-gather convs)"}.get(
+            compute, "gemm family: gemm_split_ws_kernel / gemm_split_kernel (+ gemm_f32_kernel for the NCHW-gather convs)"),
+        "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+        "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
+        "peak_note": ("fp32 MFMA dense peak" if npairs == 0 else
+                      "bf16 MFMA dense peak" if npairs == 1 else
+                      f"bf16 MFMA dense peak 2500 / {npairs} MFMAs per fp32 product; achieved counts ALGORITHMIC 2*M*N*K "
+                      f"(= {achieved / PEAK_F32_MFMA_TFLOPS:.2f}x the fp32-MFMA peak of {PEAK_F32_MFMA_TFLOPS})"),
+        "launches_per_step": launches // n, "gflop_per_step": round(fl / n / 1e9, 1), "ms_per_step": round(ms / n, 3),
+        "avg_launch_ms": round(ms / max(1, launches), 4),
+        "algorithmic_gbytes_per_step": round(by / n / 1e9, 2),
+        "measured_over": f"{n} profiled step(s) after the timed region (HIP events bracketing every launch)",
+        "families": {k: {"launches": v["launches"] // n, "ms": round(v["ms"] / n, 3), "gflop": round(v["gflop"] / n, 1),
+                         "gbytes": round(v["gbytes"] / n, 3)}
+                     for k, v in fam.items() if not k.startswith("region_")},
+    }
+    # HBM view of the memory-shaped pieces BASELINE.md C5 names: the deformable gathers (algorithmic bytes of their launches / their
+    # HIP-event time) and every launch of the ASPPDeformable modules (region_aspp), against the 8 TB/s HBM peak
+    hbm = {}
+    for key, label in (("gemm_deform_nhwc", "deform_conv_gather"), ("region_aspp", "aspp_modules")):
+        v = fam.get(key)
+        if v and v["ms"] > 0 and v["launches"] > 0:
+            gbs = v["gbytes"] / (v["ms"] * 1e-3)
+            hbm[label] = {"launches": v["launches"] // n, "ms": round(v["ms"] / n, 3), "algorithmic_gbytes": round(v["gbytes"] / n, 3),
+                          "gb_per_s": round(gbs, 1), "frac_of_hbm_peak": round(gbs / (HBM_PEAK_TBS * 1e3), 4),
+                          "tflops": round(v["gflop"] / v["ms"], 1)}
+    if hbm:
+        roof["hbm_view"] = hbm
+    return roof
+
+
 def main(argv=None):
     args = parse_args(argv)
     if args.cpu_torch_worker:
@@ -155,11 +251,14 @@ def main(argv=None):
             raise SystemExit(f"--strong: global batch {gb} does not divide over {world} ranks")
         B, scaling = gb // world, "strong"
     custom = (B, S, compute) != (cB, cS, cmode) and not args.strong
+    default_line = args.config == "c2" and not custom and not args.strong and args.deform_mode == "reference_cpu"
     also = args.also if args.also is not None else ("f32_split2,f32" if (args.config == "c2" and not custom) else "")
+    others_on = args.other_configs == "on" or (args.other_configs == "auto" and default_line)
 
     import numpy as np
     import torch
     import candle_birefnet_amd as cb
+    from candle_birefnet_amd.shard import shard_range
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU fallback)")
@@ -179,33 +278,53 @@ def main(argv=None):
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    cfg = cb.BiRefNetConfig(deform_mode=args.deform_mode)                   # BiRefNetConfig::swin_l()
-    weights = cb.synth_weights(cb.birefnet_weight_spec(cfg), seed=42)       # random-init weights of the real architecture
-    model = cb.BiRefNet.new(cfg, cb.VarBuilder.from_tensors(weights), device=local_rank, max_batch=B, max_size=(S, S), compute=compute)
-    # rank r owns images [r*B, (r+1)*B) of the global batch (seed 1000 + global index)
-    x = torch.from_numpy(cb.synth_input(B, S, S, seed0=1000 + rank * B)).cuda()
+    def all_ranks(value):
+        """[value of rank 0, ..., value of rank world-1] on every rank (control plane only: one float per rank)"""
+        if dist is None:
+            return [float(value)]
+        t = torch.zeros(world, dtype=torch.float64, device=red_dev)
+        t[rank] = float(value)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [float(v) for v in t.cpu().tolist()]
+
+    weights_cache = {}
+
+    def get_weights(cfg):
+        if "w" not in weights_cache:       # the synthetic weights do not depend on deform_mode (same names, same seed)
+            weights_cache["w"] = cb.synth_weights(cb.birefnet_weight_spec(cfg), seed=42)   # random-init weights of the real architecture
+        return weights_cache["w"]
+
+    def timed_workload(b, size, mode, deform_mode, steps, warmup, keep=False):
+        """One workload on this rank: images [start, stop) of the global batch b * world (seed 1000 + global image index), model built,
+        `warmup` untimed + `steps` timed forwards bracketed by barrier + synchronize.  Returns (seconds on this rank, per-rank seconds,
+        model, x, y); the model is closed unless keep."""
+        cfg = cb.BiRefNetConfig(deform_mode=deform_mode)                        # BiRefNetConfig::swin_l()
+        model = cb.BiRefNet.new(cfg, cb.VarBuilder.from_tensors(get_weights(cfg)), device=local_rank, max_batch=b, max_size=(size, size), compute=mode)
+        start, stop = shard_range(b * world, world, rank)                         # candle_birefnet_amd/shard.py: the tested partition
+        x = torch.from_numpy(cb.synth_input(stop - start, size, size, seed0=1000 + start)).cuda()
+        y = None
+        for _ in range(warmup):
+            y = model.forward_logits(x)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            y = model.forward_logits(x)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        per_rank = all_ranks(elapsed)
+        return max(per_rank), per_rank, cfg, model, x, y
 
     if rank == 0:
-        log(f"model built ({compute}, B={B}, {S}x{S}); warmup {args.warmup} + {args.steps} timed steps")
-    y = None
-    for _ in range(args.warmup):
-        y = model.forward_logits(x)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        y = model.forward_logits(x)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        log(f"building model ({compute}, B={B}, {S}x{S}, {args.deform_mode}); warmup {args.warmup} + {args.steps} timed steps")
+    elapsed, per_rank, cfg, model, x, y = timed_workload(B, S, compute, args.deform_mode, args.steps, args.warmup)
+    weights = get_weights(cfg)
     finite = bool(torch.isfinite(y).all().item())
 
     # ---- roofline of the dominant kernel family (the GEMM kernels), per-launch HIP events on the launch stream ----
@@ -213,52 +332,9 @@ def main(argv=None):
     stage_ms = None
     if rank == 0 and args.profile_steps > 0:
         log(f"timed region done: {elapsed / args.steps * 1e3:.3f} ms/step; profiling {args.profile_steps} step(s)")
-        model.set_profiling(True)
-        fl = ms = by = 0.0
-        launches = 0
-        fam_out = {}
-        for _ in range(args.profile_steps):
-            model.forward_logits(x)
-            st = model.last_kernel_stats()
-            for k, v in st.items():
-                a = fam_out.setdefault(k, {"launches": 0, "ms": 0.0, "gflop": 0.0, "gbytes": 0.0})
-                a["launches"] += v["launches"]; a["ms"] += v["ms"]; a["gflop"] += v["flop"] / 1e9; a["gbytes"] += v["bytes"] / 1e9
-            for k in GEMM_FAMILIES:
-                fl += st[k]["flop"]; ms += st[k]["ms"]; by += st[k]["bytes"]; launches += st[k]["launches"]
-            stage_ms = model.last_timings()
-        model.set_profiling(False)
-        n = args.profile_steps
-        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        npairs = MODES[compute][0]
-        peak = PEAK_F32_MFMA_TFLOPS if npairs == 0 else PEAK_BF16_MFMA_TFLOPS / npairs
-        # HBM-side bytes per launch of the gemm family: PMC counters cannot be read from inside this process; the figure is
-        # the committed rocprofv3 measurement of this very command (profiles/README.md), only quoted when the config matches
-        traffic, traffic_note = None, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE not collected for this configuration"
-        tj = os.path.join(ROOT, "profiles", f"r02_gemm_traffic_{args.config}_{compute}.json")
-        if os.path.exists(tj) and not custom and args.deform_mode == "reference_cpu":
-            t = json.load(open(tj))
-            traffic = round((t["hbm_read_gb_x2corrected"] + t["hbm_write_gb"]) * 1e9 / t["gemm_family_dispatches"])
-            traffic_note = (f"bytes per launch, gemm family average, from {os.path.relpath(tj, ROOT)} (rocprofv3 --pmc FETCH_SIZE x2 "
-                            "gfx950 correction + WRITE_SIZE, separate passes); algorithmic bytes per launch = "
-                            f"{round(by / n / max(1, launches // n))}")
-        roof = {
-            "bound": "mfma",
-            "kernel": {"f32": "gemm family: gemm_f32_kernel", "bf16": "gemm family: gemm_bf16_kernel (+ gemm_f32_kernel for the NCHW-gather convs)"}.get(
-                compute, "gemm family: gemm_split_ws_kernel / gemm_split_kernel (+ gemm_f32_kernel for the NCHW-gather convs)"),
-            "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
-            "peak_note": ("fp32 MFMA dense peak" if npairs == 0 else
-                          "bf16 MFMA dense peak" if npairs == 1 else
-                          f"bf16 MFMA dense peak 2500 / {npairs} MFMAs per fp32 product; achieved counts ALGORITHMIC 2*M*N*K "
-                          f"(= {achieved / PEAK_F32_MFMA_TFLOPS:.2f}x the fp32-MFMA peak of {PEAK_F32_MFMA_TFLOPS})"),
-            "launches_per_step": launches // n, "gflop_per_step": round(fl / n / 1e9, 1), "ms_per_step": round(ms / n, 3),
-            "avg_launch_ms": round(ms / max(1, launches), 4),
-            "algorithmic_gbytes_per_step": round(by / n / 1e9, 2),
-            "measured_over": f"{n} profiled step(s) after the timed region (HIP events bracketing every launch)",
-            "families": {k: {"launches": v["launches"] // n, "ms": round(v["ms"] / n, 3), "gflop": round(v["gflop"] / n, 1),
-                             "gbytes": round(v["gbytes"] / n, 3)}
-                         for k, v in fam_out.items()},
-        }
+        fam, stage_ms = profile_model(model, x, args.profile_steps)
+        roof = roofline_block(fam, args.profile_steps, compute, f"{args.config}{'_deformable' if args.deform_mode == 'deformable' else ''}_{compute}",
+                              not custom)
     barrier()
 
     # ---- CPU baseline on this box's host cores, rank 0 at N=1 only: (a) the torch-CPU restatement of the same graph
@@ -328,6 +404,42 @@ def main(argv=None):
             if ref_np is not None:
                 others[mode]["gpu_vs_oracle_max_abs_err"] = float(np.abs(y2[:1].float().cpu().numpy().astype(np.float64) - ref_np).max())
             m2.close()
+    gold_headline = golden_error(y, S, args.deform_mode) if (rank == 0 and not custom) else None
+    model.close()
+    del model, x, y
+
+    # ---- the other BASELINE configurations, driver-timed in the same run: each its own model, warm-up and timed region ----
+    other_cfgs = None
+    if others_on:
+        other_cfgs = {}
+        plan = ([("c3", "reference_cpu"), ("c3", "deformable"), ("c5", "reference_cpu"), ("c5", "deformable")] if world == 1 else
+                [("c4", "reference_cpu"), ("c4", "deformable")])
+        for cname, dm in plan:
+            oB, oS, omode, olabel = CONFIGS[cname]
+            key = cname + ("_deformable" if dm == "deformable" else "")
+            if rank == 0:
+                log(f"other config {key}: {omode}, B={oB}/GPU, {oS}x{oS}, {dm}; warmup {OTHER_WARMUP} + {OTHER_STEPS} timed steps")
+            t_o, pr_o, _, m_o, x_o, y_o = timed_workload(oB, oS, omode, dm, OTHER_STEPS, OTHER_WARMUP)
+            blk = None
+            if rank == 0:
+                g_ref = GFLOP_PER_IMAGE[oS] - (GFLOP_OFFSET_MOD_1024 * (oS / 1024) ** 2 if dm == "reference_cpu" else 0.0)
+                ips = OTHER_STEPS * oB * world / t_o
+                blk = {"workload": olabel + (f"; that per-GPU workload on each of {world} ranks" if world > 1 else ""),
+                       "images_per_s": round(ips, 3), "ms_per_step": round(t_o / OTHER_STEPS * 1e3, 3), "steps": OTHER_STEPS, "warmup": OTHER_WARMUP,
+                       "n_gpus": world, "batch_per_gpu": oB, "size": oS, "dtype": MODES[omode][1], "compute": omode, "deform_mode": dm,
+                       "outputs_finite": bool(torch.isfinite(y_o).all().item()),
+                       "reference_gflop_per_image": round(g_ref, 1),
+                       "whole_step_frac_of_mode_peak": round(ips / world * g_ref / 1e3 / PEAK_BF16_MFMA_TFLOPS, 4),
+                       "max_abs_err_image0_vs_strided_golden": golden_error(y_o, oS, dm)}
+                if world > 1:
+                    blk["per_rank_ms_per_step"] = [round(v / OTHER_STEPS * 1e3, 3) for v in pr_o]
+                fam_o, _ = profile_model(m_o, x_o, 1)
+                blk["roofline"] = roofline_block(fam_o, 1, omode, f"{key}_{omode}", True)
+            barrier()
+            m_o.close()
+            del m_o, x_o, y_o
+            if rank == 0:
+                other_cfgs[key] = blk
 
     if rank == 0:
         images = args.steps * B * world
@@ -344,10 +456,12 @@ def main(argv=None):
             "config": {"workload": workload, "baseline_config": None if custom else args.config,
                        "batch_per_gpu": B, "global_batch": B * world, "size": S, "deform_mode": args.deform_mode,
                        "compute": compute,
-                       "parallelism": f"{world} replica(s), batch-sharded, no data-path collective",
+                       "parallelism": f"{world} replica(s), batch-sharded (candle_birefnet_amd.shard.shard_range), no data-path collective",
                        "inputs": "resident in HBM (torch cuda tensors), weights: synthetic seed 42"},
             "outputs_finite": finite,
-            "roofline": roof, "cpu_baseline": cpu, "other_modes": others,
+            "per_rank_ms_per_step": [round(v / args.steps * 1e3, 3) for v in per_rank],
+            "max_abs_err_image0_vs_strided_golden": gold_headline,
+            "roofline": roof, "cpu_baseline": cpu, "other_modes": others, "other_configs": other_cfgs,
         }
         if gflop_ref:
             g = gflop_ref - (GFLOP_OFFSET_MOD_1024 * (S / 1024) ** 2 if args.deform_mode == "reference_cpu" else 0.0)
@@ -360,7 +474,6 @@ def main(argv=None):
             out["stage_ms_profiled"] = {k: round(v, 3) for k, v in stage_ms.items()}
         print(json.dumps(out), flush=True)
 
-    model.close()
     if dist is not None:
         dist.destroy_process_group()
 

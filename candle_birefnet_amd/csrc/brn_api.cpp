@@ -113,16 +113,20 @@ static void plan_model(Model& m, int B, int H, int W) {
 
 static void collect_profile(Model& m, hipStream_t s) {
     BRN_HIP(hipStreamSynchronize(s));
-    for (int f = 0; f < FAM_COUNT; ++f) { m.fam_launches[f] = 0; m.fam_ms[f] = 0.f; m.fam_flop[f] = 0.0; m.fam_bytes[f] = 0.0; }
+    for (int f = 0; f < FAM_COUNT + REGION_COUNT; ++f) { m.fam_launches[f] = 0; m.fam_ms[f] = 0.f; m.fam_flop[f] = 0.0; m.fam_bytes[f] = 0.0; }
     // BRN_DUMP_LAUNCHES=<path>: one CSV row per launch of the last profiled forward (tuning aid)
     const char* dump = getenv("BRN_DUMP_LAUNCHES");
     FILE* df = dump ? fopen(dump, "w") : nullptr;
-    if (df) fprintf(df, "family,M,N,K,ms,gflop,tflops\n");
+    if (df) fprintf(df, "family,M,N,K,ms,gflop,tflops,gbytes,region\n");
     for (auto& r : m.records) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) ms = 0.f;
-        if (df) fprintf(df, "%s,%d,%d,%d,%.4f,%.3f,%.2f\n", brn_kernel_family_name(r.fam), r.M, r.N, r.K, ms, r.flop / 1e9, ms > 0 ? r.flop / ms / 1e9 : 0.0);
+        if (df) fprintf(df, "%s,%d,%d,%d,%.4f,%.3f,%.2f,%.4f,%d\n", brn_kernel_family_name(r.fam), r.M, r.N, r.K, ms, r.flop / 1e9, ms > 0 ? r.flop / ms / 1e9 : 0.0, r.bytes / 1e9, r.region);
         m.fam_launches[r.fam]++; m.fam_ms[r.fam] += ms; m.fam_flop[r.fam] += r.flop; m.fam_bytes[r.fam] += r.bytes;
+        if (r.region > REGION_NONE && r.region < REGION_COUNT) {
+            const int g = FAM_COUNT + r.region;
+            m.fam_launches[g]++; m.fam_ms[g] += ms; m.fam_flop[g] += r.flop; m.fam_bytes[g] += r.bytes;
+        }
     }
     if (df) fclose(df);
     if (m.stage_ev_ok) {
@@ -307,16 +311,19 @@ brn_status brn_model_last_timings(brn_model* m, float ms[5]) {
 brn_status brn_model_last_kernel_stats(brn_model* m, int n, int* launches, float* ms, double* flop, double* bytes, int* n_out) {
     return guarded([&] {
         if (!m || !launches || !ms || !flop || !bytes) fail(BRN_ERR_INVALID_ARG, "null argument");
-        const int k = n < FAM_COUNT ? n : FAM_COUNT;
+        const int rows = FAM_COUNT + REGION_COUNT;      // families, then regions (row FAM_COUNT + REGION_NONE stays zero)
+        const int k = n < rows ? n : rows;
         for (int f = 0; f < k; ++f) {
             launches[f] = m->m.fam_launches[f]; ms[f] = m->m.fam_ms[f]; flop[f] = m->m.fam_flop[f]; bytes[f] = m->m.fam_bytes[f];
         }
-        if (n_out) *n_out = FAM_COUNT;
+        if (n_out) *n_out = rows;
     });
 }
 const char* brn_kernel_family_name(int f) {
     static const char* names[FAM_COUNT] = {"gemm_dense", "gemm_conv_nhwc", "gemm_gather_nchw", "gemm_deform_nhwc",
                                            "window_attention", "layernorm", "resize", "elementwise"};
+    static const char* regions[REGION_COUNT] = {"region_none", "region_aspp"};
+    if (f >= FAM_COUNT && f < FAM_COUNT + REGION_COUNT) return regions[f - FAM_COUNT];
     return (f >= 0 && f < FAM_COUNT) ? names[f] : "?";
 }
 

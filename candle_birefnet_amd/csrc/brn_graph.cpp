@@ -40,7 +40,7 @@ struct Bracket {
             }
             return (*c.event_pool)[(*c.event_next)++];
         };
-        LaunchRecord r; r.fam = fam; r.flop = flop; r.bytes = bytes; r.e0 = next(); r.e1 = next(); r.M = M; r.N = N; r.K = K;
+        LaunchRecord r; r.fam = fam; r.flop = flop; r.bytes = bytes; r.e0 = next(); r.e1 = next(); r.M = M; r.N = N; r.K = K; r.region = c.region;
         BRN_HIP(hipEventRecord(r.e0, c.stream));
         c.records->push_back(r);
     }
@@ -357,6 +357,8 @@ void decblk_forward(Ctx& c, const DecBlkW& w, const Map& in, const Map& out, int
     Map t = new_map(c, B, H, W, 64);
     run_conv(c, w.conv_in, in, t);                                   // conv_in + bn_in + relu
     const ASPPW& a = w.aspp;
+    const int region0 = c.region;
+    c.region = REGION_ASPP;
     Map cat = new_map(c, B, H, W, 1024);                             // [aspp1 | deform k1 | k3 | k7]; pooled branch -> bias
     if (deform_mode == BRN_DEFORM_REFERENCE_CPU) {
         run_gemm(c, a.k1pair, t.p, M, 64, cat.p, 1024, 0);           // aspp1 + aspp_deforms.0 (regular 1x1, BN, ReLU)
@@ -391,6 +393,7 @@ void decblk_forward(Ctx& c, const DecBlkW& w, const Map& in, const Map& out, int
     }
     Map u = new_map(c, B, H, W, 64);
     run_gemm(c, a.conv1_main, cat.p, M, 1024, u.p, 64, 0, nullptr, 0, 0, gb, H * W);   // conv1 + bn1 + relu (aspp.rs:329-331)
+    c.region = region0;
     run_conv(c, w.conv_out, u, out);                                 // conv_out + bn_out (no ReLU)
     c.arena->release(mk);
 }

@@ -33,8 +33,12 @@ enum Family {
     FAM_GEMM_DENSE = 0, FAM_GEMM_CONV, FAM_GEMM_GATHER, FAM_GEMM_DEFORM, FAM_ATTENTION, FAM_LAYERNORM,
     FAM_RESIZE, FAM_ELEMENTWISE, FAM_COUNT
 };
+// coarse graph regions, accounted beside the families (rows FAM_COUNT.. of brn_model_last_kernel_stats): the ASPPDeformable modules
+// (aspp.rs:303-333: branch convs incl. offset / modulator convs and the deformable gathers, pooled branch, conv1) — BASELINE.md C5 asks
+// for their HBM rate
+enum Region { REGION_NONE = 0, REGION_ASPP = 1, REGION_COUNT };
 
-struct LaunchRecord { int fam; double flop; double bytes; hipEvent_t e0, e1; int M, N, K; };
+struct LaunchRecord { int fam; double flop; double bytes; hipEvent_t e0, e1; int M, N, K; int region; };
 
 // ---- HBM arena: one allocation, stack discipline (mark / release) ------------------------------------------
 // In dry-run mode nothing is allocated or launched: the same graph code walks the plan and records the peak.
@@ -57,6 +61,7 @@ struct Ctx {
     std::vector<hipEvent_t>* event_pool; size_t* event_next;
     // compute mode BRN_BF16: activation maps are bf16 in HBM (esz = 2); pointers stay typed float* and are opaque to the host
     bool bf16 = false;
+    int region = REGION_NONE;       // tag of the launches being recorded (profiling only)
     int esz() const { return bf16 ? 2 : 4; }
     float* act_alloc(size_t elems) { return arena->alloc_bytes(elems * (size_t)esz()); }
     template <class T> T* at(T* p, size_t elems) const { return reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(p)) + elems * (size_t)esz()); }
@@ -180,7 +185,7 @@ struct Model {
     std::vector<hipEvent_t> event_pool; size_t event_next = 0;
     hipEvent_t stage_ev[6]; bool stage_ev_ok = false;
     float last_ms[5] = {0, 0, 0, 0, 0};
-    int fam_launches[FAM_COUNT]; float fam_ms[FAM_COUNT]; double fam_flop[FAM_COUNT]; double fam_bytes[FAM_COUNT];
+    int fam_launches[FAM_COUNT + REGION_COUNT]; float fam_ms[FAM_COUNT + REGION_COUNT]; double fam_flop[FAM_COUNT + REGION_COUNT]; double fam_bytes[FAM_COUNT + REGION_COUNT];
     ~Model();
 };
 

@@ -157,8 +157,10 @@ brn_status brn_model_decoder_forward(brn_model* m, const float* x_nchw, const fl
 brn_status brn_model_set_profiling(brn_model* m, int enable);
 brn_status brn_model_last_timings(brn_model* m, float ms[5]);
 /* Per-kernel-family accounting of the last profiled forward: for family f (see brn_kernel_family_name)
- * launches[f], ms[f] (HIP-event time around each launch, summed) and flop[f] (2*M*N*K of the launches).
- * n is the array capacity; returns the number of families through *n_out. */
+ * launches[f], ms[f] (HIP-event time around each launch, summed), flop[f] (2*M*N*K of the launches) and bytes[f] (their
+ * algorithmic operand + result bytes).  After the families come coarse graph regions counted a second time under their own
+ * rows ("region_aspp" = every launch of the ASPPDeformable modules, aspp.rs:303-333; "region_none" stays zero).
+ * n is the array capacity; returns the number of rows (families + regions) through *n_out. */
 brn_status brn_model_last_kernel_stats(brn_model* m, int n, int* launches, float* ms, double* flop,
                                        double* bytes, int* n_out);
 const char* brn_kernel_family_name(int f);
@@ -197,7 +199,8 @@ brn_status brn_upsample_bilinear2d(const float* x, int B, int C, int H, int W, i
  * pad -> roll(-shift) -> window_partition -> WindowAttention::forward (qkv, q*scale, q@k^T + rel-pos bias
  * (+ SW-MSA mask), softmax, @v, proj) -> window_reverse -> roll(+shift) -> crop.
  * x [B,H,W,C] is the norm1 output; y [B,H,W,C].  rel_table is relative_position_bias_table [(2ws-1)^2, heads].
- * head_dim must be 32 and window_size 12 (the Swin-L geometry, swin.rs:69-80). */
+ * head_dim must be 32; window_size 12 (Swin-B / L, swin.rs:55-80; every compute mode) or 7 (Swin-T / S, swin.rs:27-52); shift 0 or
+ * window_size / 2. */
 brn_status brn_window_attention_forward(const float* x, int B, int H, int W, int C, int heads, int window_size,
                                         int shift, const float* qkv_w, const float* qkv_b,
                                         const float* proj_w, const float* proj_b, const float* rel_table,

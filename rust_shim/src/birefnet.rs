@@ -222,39 +222,74 @@ pub struct BiRefNet {
     pub squeeze_module: SqueezeModule,
     pub decoder: BiRefNetDecoder,
     h: Arc<Handle>,
+    device: i32,
 }
 
 impl BiRefNet {
     /// birefnet.rs:389 — same signature.  Compute mode and deform mode of the HIP backend come from the environment
     /// (`BIREFNET_HIP_COMPUTE` = f32 | f32_split3 (default) | f32_split2 | bf16_operands | bf16; `BIREFNET_HIP_DEFORM` =
     /// reference_cpu (default) | deformable) so that the reference's call sites compile unchanged.
+    /// The HIP device and the largest batch the workspace is planned for come from `BIREFNET_HIP_DEVICE` (default 0) and
+    /// `BIREFNET_HIP_MAX_BATCH` (default 1; larger batches re-plan on first use); `new_on` takes them as arguments.
     pub fn new(config: BiRefNetConfig, vb: VarBuilder) -> Result<Self> {
+        Self::new_on(config, vb, device_from_env(), max_batch_from_env())
+    }
+
+    /// `new` on an explicit HIP device ordinal with the workspace planned for `max_batch` images: what a data-parallel caller uses,
+    /// one model (= one weight replica, one handle) per GPU of the node and a contiguous shard of the batch each — images are
+    /// independent units, there is no collective on the path (bench.py does the same with one process per GPU).
+    pub fn new_on(config: BiRefNetConfig, vb: VarBuilder, device: i32, max_batch: usize) -> Result<Self> {
         let named = ffi::NamedTensors::from_varbuilder(&vb, &weight_spec(&config))?;
         let c = config.to_c(deform_from_env())?;
         let mut raw = std::ptr::null_mut();
         ffi::check(unsafe {
-            ffi::brn_model_create(&c, named.views.as_ptr(), named.views.len(), 0, compute_from_env(), 1, config.size.1 as i32, config.size.0 as i32, &mut raw)
+            ffi::brn_model_create(&c, named.views.as_ptr(), named.views.len(), device, compute_from_env(), max_batch.max(1) as i32,
+                                  config.size.1 as i32, config.size.0 as i32, &mut raw)
         })?;
-        Ok(Self::wrap(config, raw))
+        Ok(Self::wrap(config, raw, device))
     }
 
     /// `VarBuilder::from_mmaped_safetensors(&[path], DType::F32, &device)` + `BiRefNet::new` in one call (infer_image.rs:35-40):
     /// the library memory-maps and parses the checkpoint itself, no tensor crosses the FFI
     pub fn from_safetensors(config: BiRefNetConfig, path: &std::path::Path) -> Result<Self> {
+        Self::from_safetensors_on(config, path, device_from_env(), max_batch_from_env())
+    }
+
+    /// `from_safetensors` on an explicit device / planned batch (see `new_on`)
+    pub fn from_safetensors_on(config: BiRefNetConfig, path: &std::path::Path, device: i32, max_batch: usize) -> Result<Self> {
         let p = std::ffi::CString::new(path.to_string_lossy().as_bytes()).map_err(|e| candle_core::Error::Msg(e.to_string()))?;
         let c = config.to_c(deform_from_env())?;
         let mut raw = std::ptr::null_mut();
         ffi::check(unsafe {
-            ffi::brn_model_create_from_safetensors(&c, p.as_ptr(), std::ptr::null(), 0, compute_from_env(), 1, config.size.1 as i32,
-                                                   config.size.0 as i32, &mut raw)
+            ffi::brn_model_create_from_safetensors(&c, p.as_ptr(), std::ptr::null(), device, compute_from_env(), max_batch.max(1) as i32,
+                                                   config.size.1 as i32, config.size.0 as i32, &mut raw)
         })?;
-        Ok(Self::wrap(config, raw))
+        Ok(Self::wrap(config, raw, device))
     }
 
-    fn wrap(config: BiRefNetConfig, raw: *mut ffi::BrnModel) -> Self {
+    fn wrap(config: BiRefNetConfig, raw: *mut ffi::BrnModel, device: i32) -> Self {
         let h = Arc::new(Handle(raw));
         let out_channels = config.lateral_channels()[3];
-        Self { config, backbone: Backbone { h: h.clone() }, squeeze_module: SqueezeModule { h: h.clone(), out_channels }, decoder: BiRefNetDecoder { h: h.clone() }, h }
+        Self { config, backbone: Backbone { h: h.clone() }, squeeze_module: SqueezeModule { h: h.clone(), out_channels }, decoder: BiRefNetDecoder { h: h.clone() }, h, device }
+    }
+
+    /// HIP device ordinal this model's weights and workspace live on
+    pub fn device_ordinal(&self) -> i32 {
+        self.device
+    }
+
+    /// `forward_logits` (or `forward` with `sigmoid`) on buffers that already live in this model's device memory: `x_dev` =
+    /// [b,3,h,w] f32 NCHW, `logits_dev` = [b,1,h,w] f32, both HIP device pointers; the launches are enqueued on `stream` (a
+    /// `hipStream_t`, null = the default stream) and NOT waited for.  No host staging: the `Tensor` entry points copy 12.6 MB in
+    /// and 4.2 MB out per 1024x1024 image through host `Vec<f32>`s, this one copies nothing (what bench.py times).
+    ///
+    /// # Safety
+    /// the pointers must be valid device allocations of at least those sizes on device `device_ordinal()` and stay alive until
+    /// the stream has executed the forward.
+    pub unsafe fn forward_logits_device(&self, x_dev: *const f32, b: usize, h: usize, w: usize, logits_dev: *mut f32, sigmoid: bool,
+                                        stream: *mut libc::c_void) -> Result<()> {
+        let f = if sigmoid { ffi::brn_forward } else { ffi::brn_forward_logits };
+        ffi::check(f(self.h.0, x_dev, b as i32, h as i32, w as i32, ffi::BRN_MEM_DEVICE, logits_dev, ffi::BRN_MEM_DEVICE, stream))
     }
 
     fn run(&self, x: &Tensor, sigmoid: bool) -> Result<Tensor> {
@@ -295,6 +330,12 @@ fn compute_from_env() -> i32 {
         Ok("bf16") => ffi::BRN_BF16,
         _ => ffi::BRN_F32_SPLIT3,
     }
+}
+fn device_from_env() -> i32 {
+    std::env::var("BIREFNET_HIP_DEVICE").ok().and_then(|v| v.parse().ok()).unwrap_or(0)
+}
+fn max_batch_from_env() -> usize {
+    std::env::var("BIREFNET_HIP_MAX_BATCH").ok().and_then(|v| v.parse().ok()).unwrap_or(1)
 }
 fn deform_from_env() -> i32 {
     match std::env::var("BIREFNET_HIP_DEFORM").as_deref() {

@@ -6,7 +6,7 @@ oracle and the HIP path to an independent restatement of the same Rust sources, 
 Weights and inputs are never stored: both sides regenerate them from seeds (candle_birefnet_amd.weights, numpy Philox);
 `weights_checksum` guards against PRNG drift.
 
-  python tests/golden/make_golden.py [--full1024 | --full2048]   (the 1024x1024 fp64 run takes several minutes and ~20 GB;
+  python tests/golden/make_golden.py [--full1024 | --full2048] [--deformable]   (the 1024x1024 fp64 run takes several minutes and ~20 GB;
                                                                   --full2048 runs the restatement in fp32)
 """
 import argparse
@@ -87,26 +87,30 @@ def model_goldens():
     return out
 
 
-def full1024():
-    cfg = BiRefNetConfig()
+def full1024(deform_mode="reference_cpu"):
+    """deform_mode="deformable": the Metal / upstream semantics (aspp.rs:58-165) that BASELINE configs[2..4] time (SURVEY D1);
+    stored under m1024_full_def_* in model_1024_def.npz"""
+    cfg = BiRefNetConfig(deform_mode=deform_mode)
+    tag = "ref" if deform_mode == "reference_cpu" else "def"
     w = synth_weights(birefnet_weight_spec(cfg), seed=42)
     x = synth_input(1, 1024, 1024)
     t = time.time()
     y, parts = R.forward_logits(x, w, cfg, D, return_parts=True)
     print("1024 fp64 restatement", f"{time.time() - t:.1f}s", flush=True)
     yn = y.numpy()
-    out = {"m1024_full_ref_s16": yn[:, :, ::16, ::16].astype(np.float32),
-           "m1024_full_ref_stats": np.array([yn.sum(), np.abs(yn).sum(), yn.min(), yn.max()], np.float64)}
+    out = {f"m1024_full_{tag}_s16": yn[:, :, ::16, ::16].astype(np.float32),
+           f"m1024_full_{tag}_stats": np.array([yn.sum(), np.abs(yn).sum(), yn.min(), yn.max()], np.float64)}
     for i, f in enumerate(parts["f"]):
         fn = f.numpy()
-        out[f"m1024_full_ref_f{i}_stats"] = np.array([fn.sum(), np.abs(fn).sum(), fn.min(), fn.max()], np.float64)
+        out[f"m1024_full_{tag}_f{i}_stats"] = np.array([fn.sum(), np.abs(fn).sum(), fn.min(), fn.max()], np.float64)
     return out
 
 
-def full2048():
+def full2048(deform_mode="reference_cpu"):
     """BASELINE configs[4] geometry (2048x2048, B=1) through the torch restatement in fp32 (fp64 does not fit this container's
     62 GiB): every 32nd pixel + global statistics.  fp32-vs-fp32: the GPU test's tolerance is the north-star gate."""
-    cfg = BiRefNetConfig()
+    cfg = BiRefNetConfig(deform_mode=deform_mode)
+    tag = "ref" if deform_mode == "reference_cpu" else "def"
     w = synth_weights(birefnet_weight_spec(cfg), seed=42)
     x = synth_input(1, 2048, 2048)
     t = time.time()
@@ -114,8 +118,8 @@ def full2048():
         y = R.forward_logits(x, w, cfg, torch.float32)
     print("2048 fp32 restatement", f"{time.time() - t:.1f}s", flush=True)
     yn = y.numpy().astype(np.float64)
-    return {"m2048_full_ref_s32": yn[:, :, ::32, ::32].astype(np.float32),
-            "m2048_full_ref_stats": np.array([yn.sum(), np.abs(yn).sum(), yn.min(), yn.max()], np.float64)}
+    return {f"m2048_full_{tag}_s32": yn[:, :, ::32, ::32].astype(np.float32),
+            f"m2048_full_{tag}_stats": np.array([yn.sum(), np.abs(yn).sum(), yn.min(), yn.max()], np.float64)}
 
 
 def weights_checksum():
@@ -130,12 +134,14 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full1024", action="store_true")
     ap.add_argument("--full2048", action="store_true")
+    ap.add_argument("--deformable", action="store_true", help="with --full1024 / --full2048: deform_mode=deformable -> model_<S>_def.npz")
     a = ap.parse_args()
+    dm, sfx = ("deformable", "_def") if a.deformable else ("reference_cpu", "")
     torch.set_num_threads(os.cpu_count() or 1)
     if a.full2048:
-        np.savez_compressed(os.path.join(HERE, "model_2048.npz"), **full2048())
+        np.savez_compressed(os.path.join(HERE, f"model_2048{sfx}.npz"), **full2048(dm))
     elif a.full1024:
-        np.savez_compressed(os.path.join(HERE, "model_1024.npz"), **full1024())
+        np.savez_compressed(os.path.join(HERE, f"model_1024{sfx}.npz"), **full1024(dm))
     else:
         np.savez_compressed(os.path.join(HERE, "kats.npz"), **kats())
         g = model_goldens()

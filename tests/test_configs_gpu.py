@@ -48,6 +48,63 @@ def test_c3_batch8_1024_bf16(gpu, mode):
     m.close()
 
 
+def _deform_model(mode, max_batch, size):
+    import candle_birefnet_amd as cb
+    cfg = cb.BiRefNetConfig(deform_mode="deformable")
+    w = cb.synth_weights(cb.birefnet_weight_spec(cfg), seed=42)
+    return cb, cb.BiRefNet.new(cfg, cb.VarBuilder.from_tensors(w), compute=mode, max_batch=max_batch, max_size=(size, size))
+
+
+def test_full_1024_deformable_fp32_equivalent_against_golden(gpu):
+    """deform_mode=deformable (aspp.rs:58-165, the mode SURVEY D1 assigns to configs 3-5) at the full 1024^2 Swin-L geometry in the
+    parity-graded arithmetic, against the fp64 restatement (tests/golden/model_1024_def.npz: every 16th pixel + global statistics)."""
+    import torch
+    cb, m = _deform_model("f32_split3", 1, 1024)
+    k = np.load(os.path.join(GOLD, "model_1024_def.npz"))
+    x = torch.from_numpy(cb.synth_input(1, 1024, 1024)).cuda()
+    y = m.forward_logits(x).cpu().numpy().astype(np.float64)
+    ref = k["m1024_full_def_s16"].astype(np.float64)
+    err = np.abs(y[:, :, ::16, ::16] - ref)
+    assert ((err <= 1e-3) | (err <= 1e-2 * np.abs(ref))).all(), f"max abs err {err.max():.3e}"
+    st = k["m1024_full_def_stats"]
+    assert abs(y.sum() - st[0]) <= 1e-4 * st[1] and abs(np.abs(y).sum() - st[1]) <= 1e-4 * st[1]
+    assert abs(y.min() - st[2]) <= 1e-3 and abs(y.max() - st[3]) <= 1e-3
+    print(f"1024x1024 Swin-L deformable [f32_split3]: max abs err on the strided fp64 golden {err.max():.2e}")
+    assert err.max() < 2e-4
+    m.close()
+
+
+def test_c3_batch8_1024_bf16_deformable(gpu):
+    """configs[2] / one rank of configs[3] in deform_mode=deformable (the bf16-MFMA gather kernel): B=8, 1024x1024, finite, repeatable,
+    image 0 bounded against the fp64 golden, an image alone equals the image inside the batch up to the mode's rounding."""
+    import torch
+    cb, m = _deform_model("bf16", 8, 1024)
+    x = torch.from_numpy(cb.synth_input(8, 1024, 1024)).cuda()
+    y = m.forward_logits(x)
+    assert torch.isfinite(y).all() and torch.equal(y, m.forward_logits(x))
+    k = np.load(os.path.join(GOLD, "model_1024_def.npz"))
+    yn = y.cpu().numpy().astype(np.float64)
+    e0 = float(np.abs(yn[0, :, ::16, ::16] - k["m1024_full_def_s16"][0]).max())
+    d = float(np.abs(m.forward_logits(x[5:6]).cpu().numpy().astype(np.float64)[0] - yn[5]).max())
+    print(f"c3 deformable [bf16] B=8 1024^2: max abs err of image 0 vs the fp64 golden {e0:.3e}; image alone vs in batch {d:.3e}")
+    assert e0 < BF16_ABS_BOUND["bf16"] and d < BF16_ABS_BOUND["bf16"]
+    m.close()
+
+
+def test_c5_batch4_2048_bf16_deformable(gpu):
+    """configs[4] in deform_mode=deformable: B=4, 2048x2048 (dec1's ASPP gathers on 512^2 maps), against the fp32 restatement."""
+    import torch
+    cb, m = _deform_model("bf16", 4, 2048)
+    k = np.load(os.path.join(GOLD, "model_2048_def.npz"))
+    x = torch.from_numpy(cb.synth_input(4, 2048, 2048)).cuda()
+    y = m.forward_logits(x)
+    assert torch.isfinite(y).all() and torch.equal(y, m.forward_logits(x))
+    e0 = float(np.abs(y.cpu().numpy().astype(np.float64)[0, :, ::32, ::32] - k["m2048_full_def_s32"][0]).max())
+    print(f"c5 deformable [bf16] B=4 2048^2: max abs err of image 0 vs the fp32 golden {e0:.3e}")
+    assert e0 < BF16_ABS_BOUND["bf16"]
+    m.close()
+
+
 def test_c5_2048_fp32_equivalent_against_golden(gpu):
     """configs[4] geometry, B=1, in the parity-graded arithmetic: every 32nd pixel + global statistics of the fp32 restatement."""
     import torch

@@ -100,6 +100,18 @@ def main():
         for bad in ("todo!(", "unimplemented!(", "unreachable!("):
             if bad in t:
                 errs.append(f"rust_shim/src/{fn} contains {bad})")
+    # the data-parallel / zero-copy surface: device ordinal and planned batch come from the caller, a
+    # device-pointer forward exists, and no brn_model_create* call site hard-wires device 0 / max_batch 1
+    b = open(os.path.join(ROOT, "rust_shim", "src", "birefnet.rs")).read()
+    for need in ("pub fn new_on(config: BiRefNetConfig, vb: VarBuilder, device: i32, max_batch: usize)",
+                 "pub fn from_safetensors_on(", "pub unsafe fn forward_logits_device(", "pub fn device_ordinal(&self)",
+                 "BIREFNET_HIP_DEVICE", "BIREFNET_HIP_MAX_BATCH", "ffi::BRN_MEM_DEVICE"):
+        if need not in b:
+            errs.append(f"rust_shim/src/birefnet.rs lacks `{need}`")
+    for m in re.finditer(r"ffi::brn_model_create(?:_from_safetensors)?\((.*?)\)\s*\n?\s*\}\)", b, re.S):
+        args = [a.strip() for a in " ".join(m.group(1).split()).split(",")]
+        if "device" not in args or not any(a.startswith("max_batch") for a in args):
+            errs.append(f"a brn_model_create call site does not pass the caller's device / max_batch: {args}")
     for e in errs:
         print("MISMATCH:", e)
     print(f"{len(hf)} header entry points, {len(rf)} in hip_ffi.rs, {len(errs)} problem(s)")
