@@ -747,6 +747,10 @@ brn_status brn_deform_conv2d_forward(const float* x, int B, int C, int H, int W,
         const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1, kk = k * k;
         ensure_device(device);
         DeviceOwner own;
+        // compute mode BRN_BF16 at op level (brn_set_op_compute): bf16 map in / out as inside the model, offsets / modulator fp32, the
+        // gather on kernels/deform_bf16.hip where the shape allows; every other mode runs the fp32-MFMA gather kernel
+        const bool bf = g_op_planes == BUILD_BF16 && C >= 64 && (C % 64) == 0 && (O % 8) == 0;
+        struct Planes { Planes(int p) { set_build_planes(p); } ~Planes() { set_build_planes(0); } } planes_guard(bf ? BUILD_BF16 : 0);
         std::vector<float> w3((size_t)3 * kk * C * kk), b3((size_t)3 * kk);
         memcpy(w3.data(), offset_w, (size_t)2 * kk * C * kk * sizeof(float));
         memcpy(w3.data() + (size_t)2 * kk * C * kk, mod_w, (size_t)kk * C * kk * sizeof(float));
@@ -756,6 +760,7 @@ brn_status brn_deform_conv2d_forward(const float* x, int B, int C, int H, int W,
         om.mode = GEMM_CONV_NHWC;
         GemmW reg = make_conv_nhwc(own, w, bias, O, C, C, k, k, stride, pad, 1);
         reg.mode = GEMM_DEFORM_NHWC;
+        if (bf) attach_deform_frags(own, reg, w);
         Staging st(stream, loc);
         const float* dx = st.in(x, (size_t)B * C * H * W);
         float* dy = st.out(y, (size_t)B * O * Ho * Wo);
@@ -764,12 +769,13 @@ brn_status brn_deform_conv2d_forward(const float* x, int B, int C, int H, int W,
             const int ldom = (3 * kk + 3) / 4 * 4;
             Map OM; OM.B = B; OM.H = Ho; OM.W = Wo; OM.C = 3 * kk; OM.ld = ldom; OM.coff = 0;
             OM.p = c.arena->alloc((size_t)B * Ho * Wo * ldom);
-            if (!c.dry) BRN_HIP(launch_nchw_to_nhwc(dx, B, C, H, W, X.p, X.ld, 0, c.stream));
-            run_conv(c, om, X, OM);
-            if (!c.dry) BRN_HIP(launch_mod_sigmoid2(OM.p, (size_t)B * Ho * Wo, ldom, 2 * kk, 3 * kk, c.stream));
-            run_conv(c, reg, X, Y, OM.p, ldom, 2 * kk);
-            if (!c.dry) BRN_HIP(launch_nhwc_to_nchw(Y.p, B, O, Ho, Wo, Y.ld, 0, dy, c.stream));
-        });
+            if (!c.dry) BRN_HIP(launch_nchw_to_nhwc(dx, B, C, H, W, X.p, X.ld, 0, c.stream, c.bf16));
+            run_conv(c, om, X, OM, nullptr, 0, 0, 1);
+            const bool fused_sig = deform_fused_sigmoid(c, reg);
+            if (!c.dry && !fused_sig) BRN_HIP(launch_mod_sigmoid2(OM.p, (size_t)B * Ho * Wo, ldom, 2 * kk, 3 * kk, c.stream));
+            run_conv(c, reg, X, Y, OM.p, ldom, 2 * kk, 0, fused_sig ? 1 : 0);
+            if (!c.dry) BRN_HIP(launch_nhwc_to_nchw(Y.p, B, O, Ho, Wo, Y.ld, 0, dy, c.stream, c.bf16));
+        }, bf);
         st.finish();
     });
 }

@@ -115,7 +115,26 @@ void run_gemm(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* C, 
     else BRN_LAUNCH(launch_gemm(p, pl, ws, c.stream));
 }
 
-void run_conv(Ctx& c, const GemmW& w, const Map& in, const Map& out, const float* om, int om_ld, int om_mask_off, int c_f32) {
+// geometry + operands of a deformable conv on kernels/deform_bf16.hip (compute mode BRN_BF16)
+static GemmParams deform_bf16_params(const GemmW& w, const Map& in, const Map& out, int Hout, int Wout, const float* om, int om_ld, int om_mask_off,
+                                     int om_sigmoid) {
+    GemmParams p{};
+    p.A = in.p; p.C = out.p; p.M = out.B * Hout * Wout; p.N = w.N; p.K = w.K; p.mode = GEMM_DEFORM_NHWC;
+    p.lda = in.ld; p.a_coff = in.coff;
+    p.Hin = in.H; p.Win = in.W; p.Cin = w.Cinp; p.kh = w.kh; p.kw = w.kw; p.stride = w.stride; p.pad = w.pad; p.dil = w.dil;
+    p.Hout = Hout; p.Wout = Wout; p.Kreal = w.Kreal;
+    p.om = om; p.om_ld = om_ld; p.om_mask_off = om_mask_off; p.om_sigmoid = om_sigmoid;
+    p.bias = w.bias; p.scale = w.scale; p.shift = w.shift; p.act = w.act;
+    p.bbias_rows = 1; p.ldc = out.ld; p.c_coff = out.coff;
+    p.Wp = w.wf; p.planes = 1;
+    return p;
+}
+bool deform_fused_sigmoid(const Ctx& c, const GemmW& w) {
+    static const bool off = getenv("BRN_DEFORM_F32_KERNEL") && atoi(getenv("BRN_DEFORM_F32_KERNEL")) != 0;   // A/B: the fp32-MFMA gather kernel
+    return c.bf16 && w.mode == GEMM_DEFORM_NHWC && w.wf && !off && w.Cinp % 64 == 0 && (w.N & 7) == 0 && w.act != ACT_GELU_ERF;
+}
+
+void run_conv(Ctx& c, const GemmW& w, const Map& in, const Map& out, const float* om, int om_ld, int om_mask_off, int c_f32, int om_sigmoid) {
     const int Hout = (in.H + 2 * w.pad - w.dil * (w.kh - 1) - 1) / w.stride + 1;
     const int Wout = (in.W + 2 * w.pad - w.dil * (w.kw - 1) - 1) / w.stride + 1;
     if (out.H != Hout || out.W != Wout || out.B != in.B || out.C != w.N)
@@ -139,6 +158,20 @@ void run_conv(Ctx& c, const GemmW& w, const Map& in, const Map& out, const float
         run_gemm_bf16(c, w, p, FAM_GEMM_CONV);
         return;
     }
+    if (deform_fused_sigmoid(c, w) && !c_f32) {
+        if (!om) fail(BRN_ERR_INVALID_ARG, "deformable conv without an offset/modulator map");
+        GemmParams p = deform_bf16_params(w, in, out, Hout, Wout, om, om_ld, om_mask_off, om_sigmoid);
+        if (deform_bf16_eligible(p)) {
+            if (c.dry) return;
+            const double flop = 2.0 * M * (double)w.N * w.K;
+            // algorithmic bytes: the sampled map once, the offset / modulator map, the weights, the result
+            const double bytes = 2.0 * ((double)in.pixels() * w.Cinp + (double)w.N * w.K + (double)M * w.N) + 4.0 * M * 3.0 * w.kh * w.kw;
+            Bracket b(c, FAM_GEMM_DEFORM, flop, bytes, M, w.N, w.K);
+            BRN_LAUNCH(launch_deform_bf16(p, c.stream));
+            return;
+        }
+        if (om_sigmoid) fail(BRN_ERR_INVALID_ARG, "deformable conv: raw modulator logits passed to a shape the bf16 gather kernel does not cover");
+    } else if (om_sigmoid) fail(BRN_ERR_INVALID_ARG, "deformable conv: raw modulator logits outside the bf16 gather kernel");
     GemmPlan pl = plan_gemm(M, w.N, w.K, (w.wp && w.mode == GEMM_CONV_NHWC) ? w.planes : 0);
     if (c.bf16) { pl.splitk = 1; pl.ws_floats = 0; }     // (the fp32 split-K reduce pass has no bf16 output; deformable convs only)
     const size_t mk = c.arena->mark();
@@ -372,11 +405,12 @@ void decblk_forward(Ctx& c, const DecBlkW& w, const Map& in, const Map& out, int
             Map om; om.B = B; om.H = H; om.W = W; om.C = 3 * kk; om.ld = ldom; om.coff = 0;
             om.p = c.arena->alloc((size_t)M * ldom);                 // offsets / modulator stay fp32 in every mode
             run_conv(c, d.offmod, t, om, nullptr, 0, 0, 1);          // offset_conv | modulator_conv (aspp.rs:171,173)
-            if (!c.dry) {
+            const bool fused_sig = deform_fused_sigmoid(c, d.regular);   // bf16 gather kernel: 2*sigmoid applied where the modulator is read
+            if (!c.dry && !fused_sig) {
                 Bracket b(c, FAM_ELEMENTWISE, 0.0, 8.0 * M * kk);
                 BRN_LAUNCH(launch_mod_sigmoid2(om.p, (size_t)M, ldom, 2 * kk, 3 * kk, c.stream));   // 2*sigmoid (aspp.rs:174)
             }
-            run_conv(c, d.regular, t, cat.window(256 * i, 256), om.p, ldom, 2 * kk);
+            run_conv(c, d.regular, t, cat.window(256 * i, 256), om.p, ldom, 2 * kk, 0, fused_sig ? 1 : 0);
             c.arena->release(mk2);
         }
     }

@@ -85,6 +85,7 @@ struct GemmW {          // one Linear / Conv2d, repacked for gemm_f32
     int planes = 0, wp_rows = 0;
     void* wb = nullptr; // bf16-storage mode (BRN_BF16): plain [wb_rows][wb_ld] bf16, rows padded to 256, K padded to 64 (zeros)
     int wb_rows = 0, wb_ld = 0;
+    void* wf = nullptr; // bf16-storage mode, deformable convs: the same matrix in MFMA fragment order [n/16][K/64][2][64 lanes][8] (kernels/deform_bf16.hip)
     int N = 0, K = 0, Kreal = 0;
     int Cin = 0, Cinp = 0, kh = 1, kw = 1, stride = 1, pad = 0, dil = 1;
     int mode = GEMM_DENSE;
@@ -209,7 +210,11 @@ void run_gemm(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* C, 
               int a_planes = 0, int c_planes = 0 /* 2: operand in the P2 layout (kernels/split_planes.h) */,
               int c_f32 = 0, int r_f32 = 0 /* compute mode BRN_BF16 only: C written / R read as fp32 (the residual stream) */);
 void run_conv(Ctx& c, const GemmW& w, const Map& in, const Map& out, const float* om = nullptr, int om_ld = 0, int om_mask_off = 0,
-              int c_f32 = 0);
+              int c_f32 = 0, int om_sigmoid = 0 /* the modulator columns are raw logits (only with deform_fused_sigmoid(c, w)) */);
+// true when the deformable conv `w` runs on kernels/deform_bf16.hip, which applies 2 * sigmoid to the modulator itself
+bool deform_fused_sigmoid(const Ctx& c, const GemmW& w);
+// bf16-storage mode: attach the fragment-ordered copy of a channels-last conv weight (w: candle [O][Cin][kh][kw]) for deform_bf16
+void attach_deform_frags(DeviceOwner& own, GemmW& g, const float* w_oihw);
 void run_conv_nchw(Ctx& c, const GemmW& w, const float* x_nchw, int B, int Hin, int Win, const Map& out, bool pad_to_stride = false);
 void run_layernorm(Ctx& c, const LNW& ln, const float* x, int rows, int ldx, float* y, int ldy, int y_coff, int y_planes = 0, int y_bf16 = 0);
 void run_resize(Ctx& c, const Map& in, const Map& out);

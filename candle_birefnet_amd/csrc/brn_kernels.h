@@ -29,6 +29,7 @@ struct GemmParams {
     // deformable (mode 3): om = [B,Hout,Wout,om_ld] holding 2*kh*kw offsets (dy,dx interleaved, torchvision
     // order) then kh*kw modulator logits (already 2*sigmoid applied) starting at column om_mask_off
     const float* om; int om_ld; int om_mask_off;
+    int om_sigmoid;       // deform_bf16 kernel only: the modulator columns hold raw logits, 2 * sigmoid (aspp.rs:173-174) is applied in the gather
     // epilogue:  v = acc (+ bias[n]) (+ bbias[m / bbias_rows][n]);  v = v*scale[n] + shift[n];  v = act(v);
     //            v += R[m*ldr + r_coff + n];  C[m*ldc + c_coff + n] = v
     const float* bias;
@@ -58,6 +59,11 @@ hipError_t launch_gemm(const GemmParams& p, const GemmPlan& plan, float* ws, hip
 // bf16-storage mode: plan + launch (kernels/gemm_bf16.hip).  cfg: 0 = 128x128, 1 = 128x64, 2 = 256x256, 3 = 256x192 block tile
 GemmPlan plan_gemm_bf16(int M, int N, int K, bool f32_residual = false, bool gelu = false);   // f32_residual: fp32 C with an fp32 residual (proj / fc2)
 hipError_t launch_gemm_bf16(const GemmParams& p, const GemmPlan& plan, float* ws, hipStream_t s);
+
+// bf16-storage mode, modulated deformable conv (kernels/deform_bf16.hip): A = bf16 channels-last map, om = fp32 offsets | modulator,
+// Wp = the weights in MFMA fragment order (GemmW::wf), C = bf16 window.  eligible(): shapes the kernel covers (else gemm_f32_kernel)
+bool deform_bf16_eligible(const GemmParams& p);
+hipError_t launch_deform_bf16(const GemmParams& p, hipStream_t s);
 
 // split modes with A already in the P layout (kernels/gemm_planes.hip): LDS-DMA staged, persistent, no splitting wave
 bool gemm_planes_eligible(const GemmParams& p);

@@ -157,6 +157,28 @@ GemmW make_conv_nhwc(DeviceOwner& own, const float* w, const float* bias, int O,
     return g;
 }
 
+// bf16-storage mode, deformable convs: W[n][k] (k = (ky, kx, ci), ci padded to Cinp) as bf16 in the order the MFMA consumes it —
+// fragment (n16 block nb, K step kt of 64, k32 half s) is 1 KiB: lane l = 16 (k / 8 % 4) + n % 16 holds 8 consecutive k — so a
+// wave's fragment load in kernels/deform_bf16.hip is one contiguous read.  Rows padded to 256 with zeros.
+void attach_deform_frags(DeviceOwner& own, GemmW& g, const float* w) {
+    if (g_build_planes != BUILD_BF16 || g.Cinp % 64 || g.K != g.kh * g.kw * g.Cinp) return;
+    const int nk = g.K / 64, nb_n = roundup(g.N, 256) / 16, kk = g.kh * g.kw;
+    std::vector<uint16_t> wf((size_t)nb_n * nk * 2 * 64 * 8, 0);
+    for (int n = 0; n < g.N; ++n)
+        for (int t = 0; t < kk; ++t)
+            for (int ci = 0; ci < g.Cin; ++ci) {
+                const int k = t * g.Cinp + ci;
+                const int kt = k >> 6, s = (k >> 5) & 1, lane = ((k >> 3) & 3) * 16 + (n & 15), e = k & 7;
+                wf[((((size_t)(n >> 4) * nk + kt) * 2 + s) * 64 + lane) * 8 + e] = bf16_rne(w[((size_t)n * g.Cin + ci) * kk + t]);
+            }
+    void* d = nullptr;
+    hipError_t e = hipMalloc(&d, wf.size() * 2 + 16);
+    if (e != hipSuccess) fail(BRN_ERR_OOM, "hipMalloc of %zu bytes failed: %s", wf.size() * 2, hipGetErrorString(e));
+    own.ptrs.push_back(d);
+    BRN_HIP(hipMemcpy(d, wf.data(), wf.size() * 2, hipMemcpyHostToDevice));
+    g.wf = d;
+}
+
 GemmW make_conv_gather(DeviceOwner& own, const float* w, const float* bias, int O, int Cin, int kh, int kw, int stride,
                        int pad, int dil) {
     GemmW g;
@@ -300,6 +322,7 @@ void build_decblk_weights(const WeightTable& wt, const std::string& p, int cin, 
         d.regular = conv_bn(wt, cp + "regular_conv", false, mods[i] + "bn", PL, IC, IC, k, k / 2, ACT_RELU, own);
         if (deform_mode == BRN_DEFORM_DEFORMABLE) {
             d.regular.mode = GEMM_DEFORM_NHWC;
+            attach_deform_frags(own, d.regular, wt.get(cp + "regular_conv.weight", {PL, IC, k, k})->data);
             std::vector<float> w3((size_t)3 * kk * IC * kk), b3((size_t)3 * kk);
             memcpy(w3.data(), ow, (size_t)2 * kk * IC * kk * sizeof(float));
             memcpy(w3.data() + (size_t)2 * kk * IC * kk, mw, (size_t)kk * IC * kk * sizeof(float));

@@ -1,0 +1,228 @@
+// deform_bf16.hip — the modulated deformable convolution of compute mode BRN_BF16 on the bf16 matrix cores.
+// Replaces DeformConvASPP::forward_metal / DeformableConv2d::forward_metal (aspp.rs:58-165, deform_conv.rs:101-215: deformable
+// im2col -> [Cin k^2, B Ho Wo] column matrix -> matmul) for bf16 channels-last maps: the bilinear gather x modulator is the A-tile
+// loader of an MFMA GEMM, the column matrix is never formed.  Sampling semantics (torchvision deform_conv2d): offset
+// channel 2t = dy, 2t + 1 = dx of tap t = ky kw + kx; sample at (oy stride - pad + ky + dy, ox stride - pad + kx + dx), bilinear,
+// zero outside (-1, H) x (-1, W), corners outside the image contribute zero; x modulator (2 sigmoid, aspp.rs:173-174); one offset group.
+//
+// Structure.  One workgroup (4 waves) owns 64 output pixels x 256 output channels; a K step is one tap x 64 input channels.
+//   * A tile (64 pixels x 64 channels, bf16, 8 KB, two buffers): thread t gathers chunk c = t & 7 (8 channels = 16 bytes) of rows
+//     t >> 3 and (t >> 3) + 32: four 16-byte corner loads each (8 lanes = one 128-byte pixel row: coalesced), fp32 bilinear
+//     combination x modulator, one v_cvt_pk per pair, ds_write_b128 into the XOR-swizzled image of gemm_bf16.hip (rows 2p, 2p+1
+//     share a 256-byte bank row whose sixteen 16-byte slots are permuted by p & 15: conflict-free fragment reads).  Corner addresses
+//     are clamped into the image and the corner's weight is zeroed instead of predicating the load (no exec branches around loads:
+//     the loads of K step t+1 stay in flight under the MFMAs of step t).
+//   * W never touches LDS: the four waves own disjoint 64-column slices (no reuse inside the workgroup), and the weights are
+//     stored at load time in MFMA fragment order — [n / 16][K step][k32 half][lane][8 bf16] — so a wave's fragment load is one
+//     contiguous 1-KiB read (brn_weights.cpp, attach_deform_frags).
+//   * v_mfma_f32_16x16x32_bf16, transposed product (W fragment first): a lane holds 4 consecutive output channels of one pixel.
+//   * epilogue: bias / folded BN / ReLU on the fp32 accumulators, bf16 rows through LDS (XOR-ed 16-byte chunks), stored as whole
+//     512-byte pixel rows (16 bytes per lane) into the consumer's column window.
+// Bound: the gather (4 x 128 bytes per pixel and K step from L1 / L2) and its VALU work, not the matrix pipe: per K step a wave
+// issues 32 MFMAs (512 matrix-pipe cycles) beside ~230 vector instructions.
+#include "../brn_kernels.h"
+#include "split_planes.h"
+
+namespace brn {
+
+typedef float f32x4_d __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_d __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_d __attribute__((ext_vector_type(2)));
+
+constexpr int DBM = 64, DBN = 256, DBK = 64;
+
+__device__ __forceinline__ unsigned dpack2(float lo, float hi) {
+    typedef __bf16 bf16x2_d __attribute__((ext_vector_type(2)));
+    const bf16x2_d t = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, t);
+}
+// byte offset of 16-byte chunk c (0..7) of tile row r (128-byte rows) in the swizzled A image
+__device__ __forceinline__ int a_slot(int r, int c) { return (r >> 1) * 256 + (((((r & 1) << 3) | c) ^ ((r >> 1) & 15)) << 4); }
+
+__global__ void __launch_bounds__(256, 2) gemm_deform_bf16_kernel(const GemmParams p) {
+    __shared__ __attribute__((aligned(1024))) char smem[DBM * DBN * 2];   // K loop: two 8-KB A tiles; epilogue: [64][256] bf16
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // XCD-aware tile order (bijective): the workgroups that share an L2 walk a contiguous run of pixel tiles (neighbouring image rows)
+    const int tilesM = (p.M + DBM - 1) / DBM, tilesN = (p.N + DBN - 1) / DBN;
+    int swz;
+    {
+        const int nwg = gridDim.x, orig = blockIdx.x;
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int tile_n = swz / tilesM, tile_m = swz - tile_n * tilesM;     // (tilesN is 1 for the ASPP modules)
+    const int m0 = tile_m * DBM, n0 = tile_n * DBN;
+    (void)tilesN;
+
+    // ---- gather state of this thread's two rows ----
+    const int gc = tid & 7, gr = tid >> 3;
+    const __bf16* Ab = reinterpret_cast<const __bf16*>(p.A);
+    const char* a_img[2];        // first byte of (image b, channel a_coff + 8 gc)
+    const float* om_row[2];
+    int iy0[2], ix0[2];
+    bool rok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + gr + 32 * i;
+        rok[i] = m < p.M;
+        const int mm = rok[i] ? m : p.M - 1;
+        const int hw = p.Hout * p.Wout;
+        const int b = mm / hw, rem = mm - b * hw;
+        const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+        iy0[i] = oy * p.stride - p.pad;
+        ix0[i] = ox * p.stride - p.pad;
+        a_img[i] = reinterpret_cast<const char*>(Ab + (long)b * p.Hin * p.Win * p.lda + p.a_coff + gc * 8);
+        om_row[i] = p.om + (long)mm * p.om_ld;
+    }
+    const int cpt = p.Cin / DBK;                     // K steps per tap
+    const int nk = p.K / DBK;
+    const int pix_bytes = p.lda * 2;
+
+    u32x4_d gv[2][4];
+    float gw[2][4];
+    auto gather_issue = [&](int kt) {
+        const int tap = kt / cpt, ci0 = (kt - tap * cpt) * DBK;
+        const int ky = tap / p.kw, kx = tap - ky * p.kw;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float offy = om_row[i][2 * tap], offx = om_row[i][2 * tap + 1];
+            float mk = om_row[i][p.om_mask_off + tap];
+            if (p.om_sigmoid) mk = (1.0f / (1.0f + __expf(-mk))) * 2.0f;          // aspp.rs:173-174
+            const float y = (float)(iy0[i] + ky * p.dil) + offy;
+            const float x = (float)(ix0[i] + kx * p.dil) + offx;
+            const bool inside = rok[i] && y > -1.f && y < (float)p.Hin && x > -1.f && x < (float)p.Win;
+            const float yf = floorf(y), xf = floorf(x);
+            const int yl = (int)yf, xl = (int)xf, yh = yl + 1, xh = xl + 1;
+            const float ly = y - yf, lx = x - xf, hy = 1.f - ly, hx = 1.f - lx;
+            const float s = inside ? mk : 0.f;
+            const bool yl_ok = yl >= 0, yh_ok = yh <= p.Hin - 1, xl_ok = xl >= 0, xh_ok = xh <= p.Win - 1;
+            gw[i][0] = (yl_ok && xl_ok) ? s * (hy * hx) : 0.f;
+            gw[i][1] = (yl_ok && xh_ok) ? s * (hy * lx) : 0.f;
+            gw[i][2] = (yh_ok && xl_ok) ? s * (ly * hx) : 0.f;
+            gw[i][3] = (yh_ok && xh_ok) ? s * (ly * lx) : 0.f;
+            // clamped corners: always a valid address (the value is multiplied by a zero weight when it is not a real corner);
+            // integer clamps on the float->int results also tame NaN / huge offsets
+            const int ylc = min(max(yl, 0), p.Hin - 1), yhc = min(max(yh, 0), p.Hin - 1);
+            const int xlc = min(max(xl, 0), p.Win - 1), xhc = min(max(xh, 0), p.Win - 1);
+            const char* base = a_img[i] + ci0 * 2;
+            gv[i][0] = *reinterpret_cast<const u32x4_d*>(base + (long)(ylc * p.Win + xlc) * pix_bytes);
+            gv[i][1] = *reinterpret_cast<const u32x4_d*>(base + (long)(ylc * p.Win + xhc) * pix_bytes);
+            gv[i][2] = *reinterpret_cast<const u32x4_d*>(base + (long)(yhc * p.Win + xlc) * pix_bytes);
+            gv[i][3] = *reinterpret_cast<const u32x4_d*>(base + (long)(yhc * p.Win + xhc) * pix_bytes);
+        }
+    };
+    auto gather_finish = [&](char* abuf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            u32x4_d o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float lo = 0.f, hi = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    lo = fmaf(gw[i][c], __builtin_bit_cast(float, gv[i][c][e] << 16), lo);
+                    hi = fmaf(gw[i][c], __builtin_bit_cast(float, gv[i][c][e] & 0xffff0000u), hi);
+                }
+                o[e] = dpack2(lo, hi);
+            }
+            *reinterpret_cast<u32x4_d*>(abuf + a_slot(gr + 32 * i, gc)) = o;
+        }
+    };
+
+    // ---- fragments ----
+    // W: fragment (nb, kt, s) = 1 KiB at wf + (((nb nk + kt) 2 + s) 64 + lane) 16 bytes; this wave owns n16 blocks n0/16 + 4 wave + j
+    const char* wf = reinterpret_cast<const char*>(p.Wp) + ((long)((n0 >> 4) + 4 * wave) * nk * 2 * 64 + lane) * 16;
+    const long wf_nb = (long)nk * 2 * 1024;          // bytes between consecutive n16 blocks
+    // A: lane reads tile row 16 i + (lane & 15), chunk 4 s + (lane >> 4)
+    int a_foff[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) a_foff[i][s] = a_slot(16 * i + (lane & 15), 4 * s + (lane >> 4));
+
+    f32x4_d acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_d{0.f, 0.f, 0.f, 0.f};
+
+    gather_issue(0);
+    gather_finish(smem);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* abuf = smem + (kt & 1) * (DBM * DBK * 2);
+        bf16x8 wfr[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) wfr[j][s] = *reinterpret_cast<const bf16x8*>(wf + j * wf_nb + (long)(kt * 2 + s) * 1024);
+        if (kt + 1 < nk) gather_issue(kt + 1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 af[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(abuf + a_foff[i][s]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[j][s], af[i], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) gather_finish(smem + ((kt + 1) & 1) * (DBM * DBK * 2));
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds pixel 16 i + (lane & 15), channels 64 wave + 16 j + 4 (lane >> 4) + {0..3} ----
+    {
+        const int q4 = lane >> 4, pr = lane & 15;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nl = 64 * wave + 16 * j + 4 * q4;          // channel within the tile
+            const int n = n0 + nl;
+            f32x4_d bias = {0.f, 0.f, 0.f, 0.f}, sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            if (n < p.N) {                                         // N % 4 == 0 (launcher)
+                if (p.bias) bias = *reinterpret_cast<const f32x4_d*>(p.bias + n);
+                if (p.scale) { sc = *reinterpret_cast<const f32x4_d*>(p.scale + n); sh = *reinterpret_cast<const f32x4_d*>(p.shift + n); }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4_d v = (acc[i][j] + bias) * sc + sh;
+                if (p.act == ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                const int row = 16 * i + pr;
+                const int chunk = (nl >> 3) ^ (row & 31);          // 32 chunks of 16 bytes per 512-byte row
+                const u32x2_d o = {dpack2(v[0], v[1]), dpack2(v[2], v[3])};
+                *reinterpret_cast<u32x2_d*>(smem + row * (DBN * 2) + chunk * 16 + (nl & 4) * 2) = o;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        __bf16* Cb = reinterpret_cast<__bf16*>(p.C);
+#pragma unroll
+        for (int ps = 0; ps < DBM / 8; ++ps) {
+            const int row = ps * 8 + (tid >> 5), c = tid & 31;
+            const int m = m0 + row, n = n0 + c * 8;
+            const u32x4_d v = *reinterpret_cast<const u32x4_d*>(smem + row * (DBN * 2) + ((c ^ (row & 31)) << 4));
+            if (m < p.M && n < p.N) *reinterpret_cast<u32x4_d*>(Cb + (long)m * p.ldc + p.c_coff + n) = v;   // N % 8 == 0 (launcher)
+        }
+    }
+}
+
+bool deform_bf16_eligible(const GemmParams& p) {
+    return p.mode == GEMM_DEFORM_NHWC && p.Wp && p.om && p.Cin >= DBK && (p.Cin % DBK) == 0 && p.K == p.kh * p.kw * p.Cin && (p.N & 7) == 0 &&
+           ((p.lda | p.a_coff | p.ldc | p.c_coff) & 7) == 0 && !p.R && !p.bbias && !p.c_f32 && p.act != ACT_GELU_ERF &&
+           (double)p.Hin * p.Win * p.lda * 2.0 < 2147483648.0;
+}
+
+hipError_t launch_deform_bf16(const GemmParams& p, hipStream_t s) {
+    if (!deform_bf16_eligible(p) || p.M <= 0) return hipErrorInvalidValue;
+    const int tiles = ((p.M + DBM - 1) / DBM) * ((p.N + DBN - 1) / DBN);
+    hipLaunchKernelGGL(gemm_deform_bf16_kernel, dim3(tiles), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace brn

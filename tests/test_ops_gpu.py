@@ -282,6 +282,40 @@ def test_conv2d_bf16_mode(gpu, B, C, H, W, O, k, p):
     assert (err <= 2.0 ** -8 * np.abs(ref) + 1e-6).all(), f"max abs err {err.max():.3e}"
 
 
+@pytest.mark.parametrize("k,stride,pad,O,H,C", [(3, 1, 1, 128, 32, 64), (1, 1, 0, 256, 8, 64), (7, 1, 3, 256, 12, 64), (3, 2, 1, 64, 16, 64), (3, 1, 1, 256, 19, 128),
+                                                (1, 1, 0, 256, 40, 64), (7, 1, 3, 32, 9, 64)])
+def test_deform_conv2d_bf16_mode(gpu, k, stride, pad, O, H, C):
+    """kernels/deform_bf16.hip (the bf16-MFMA gather of compute mode bf16) against an EXACT-operand reference: x and all three
+    weights rounded to bf16, offsets / modulator / bilinear sampling / contraction in fp64 (the torchvision semantics of
+    tests/torch_ref.py, aspp.rs:77-164).  What the kernel rounds on top: the sampled column (mask x bilinear) to bf16 before the MFMA,
+    the offset conv's fp32 accumulation, the bf16 output map.  Covers stride 2, ragged maps (19, 9: pixel tiles with rows >= M),
+    Cin = 128 (two K steps per tap), N = 32 / 64 / 128 (partly filled 256-column tiles), samples outside the image."""
+    import candle_birefnet_amd as cb
+    from candle_birefnet_amd import ops
+    t = {"offset_conv.weight": rnd(2 * k * k, C, k, k, seed=1, std=1.5 * (C * k * k) ** -0.5), "offset_conv.bias": rnd(2 * k * k, seed=2, std=0.3),
+         "modulator_conv.weight": rnd(k * k, C, k, k, seed=3, std=(C * k * k) ** -0.5), "modulator_conv.bias": rnd(k * k, seed=4, std=0.1),
+         "regular_conv.weight": rnd(O, C, k, k, seed=5, std=(C * k * k) ** -0.5), "regular_conv.bias": rnd(O, seed=6, std=0.1)}
+    layer = cb.DeformableConv2d.new(C, O, k, stride, pad, cb.VarBuilder.from_tensors(t), mode="deformable")
+    x = rnd(2, C, H, H, seed=9)
+    ops.set_compute("bf16")
+    try:
+        y = layer.forward(x)
+        y2 = layer.forward(x)
+    finally:
+        ops.set_compute("f32")
+    np.testing.assert_array_equal(y, y2)
+    xt = torch.from_numpy(_bf16_round(x))
+    td = {n: torch.from_numpy(_bf16_round(a) if n.endswith("weight") else np.asarray(a, np.float64)) for n, a in t.items()}
+    off = F.conv2d(xt, td["offset_conv.weight"], td["offset_conv.bias"], stride=stride, padding=pad)
+    msk = 1.0 / (torch.exp(-F.conv2d(xt, td["modulator_conv.weight"], td["modulator_conv.bias"], stride=stride, padding=pad)) + 1.0) * 2.0
+    ref = R.deform_conv2d(xt, off, msk, td["regular_conv.weight"], td["regular_conv.bias"], stride, pad).numpy()
+    err = np.abs(np.asarray(y, np.float64) - ref)
+    # sampled columns carry <= 2^-9 relative rounding each (independent over K = C k^2 terms), the output one bf16 rounding
+    scale = np.abs(ref).max()
+    assert (err <= 2.0 ** -8 * np.abs(ref) + 4e-3 * scale).all(), f"max abs err {err.max():.3e} (|ref| max {scale:.2f})"
+    print(f"deform bf16 k{k} s{stride} O{O} H{H} C{C}: max abs err {err.max():.2e}, |ref| max {scale:.2f}")
+
+
 def test_conv2d_nan_stays_local(gpu):
     """masked (zero-padded) taps are zeroed by a bit mask / zero page, not by 0 * x: a non-finite input pixel spreads
     only over its receptive field, like candle's conv2d; before, Inf at pixel (0,0) turned every border output into NaN."""
