@@ -44,7 +44,6 @@ MODES = {
     "f32": (0, "f32 (v_mfma_f32_32x32x2_f32, exact fp32 operands)", 4),
     "f32_split3": (6, "f32 storage+accumulate; GEMM operands split error-free into 3 bf16 terms, 6 bf16 MFMAs/product (fp32-equivalent)", 4),
     "f32_split2": (3, "f32 storage+accumulate; GEMM operands split into 2 bf16 terms (16-bit mantissa), 3 bf16 MFMAs/product", 4),
-    "bf16_operands": (1, "bf16 GEMM operands, f32 storage+accumulate", 4),
     "bf16": (1, "bf16 (activations and weights stored bf16 in HBM, bf16 MFMA, f32 accumulate / LayerNorm / softmax statistics)", 2),
 }
 GEMM_FAMILIES = ("gemm_dense", "gemm_conv_nhwc", "gemm_gather_nchw", "gemm_deform_nhwc")

@@ -102,6 +102,8 @@ _sig("brn_patch_merging_forward", C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_i
 _sig("brn_deform_conv2d_forward", C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int,
      C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp)
 
+_sig("brn_aspp_deformable_forward", C.c_int, _vp, C.c_size_t, C.c_char_p, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp)
+
 _sig("brn_preprocess_image", C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp)
 _sig("brn_postprocess_mask", C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp)
 _sig("brn_set_op_compute", C.c_int, C.c_int)
@@ -116,7 +118,7 @@ DECLARED = [
     "brn_model_set_profiling", "brn_model_last_timings", "brn_model_last_kernel_stats", "brn_kernel_family_name",
     "brn_swin_create", "brn_swin_destroy", "brn_swin_forward", "brn_linear_forward", "brn_layer_norm_forward",
     "brn_conv2d_forward", "brn_upsample_bilinear2d", "brn_window_attention_forward", "brn_patch_merging_forward",
-    "brn_deform_conv2d_forward", "brn_set_op_compute", "brn_preprocess_image", "brn_postprocess_mask",
+    "brn_deform_conv2d_forward", "brn_aspp_deformable_forward", "brn_set_op_compute", "brn_preprocess_image", "brn_postprocess_mask",
 ]
 
 

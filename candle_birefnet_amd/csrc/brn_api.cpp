@@ -245,7 +245,11 @@ brn_status brn_model_create(const brn_config* cfg, const brn_named_tensor* weigh
         if (dt == BRN_F32) planes = 0;
         else if (dt == BRN_F32_SPLIT3) planes = 3;
         else if (dt == BRN_F32_SPLIT2) planes = 2;
+#ifdef BRN_DIAG_BUILD
         else if (dt == BRN_BF16_OPERANDS) planes = 1;
+#else
+        else if (dt == BRN_BF16_OPERANDS) fail(BRN_ERR_INVALID_ARG, "compute dtype BRN_BF16_OPERANDS is superseded by BRN_BF16 and only built into libbirefnet_hip_diag.so");
+#endif
         else if (dt == BRN_BF16) planes = BUILD_BF16;
         else fail(BRN_ERR_INVALID_ARG, "unsupported compute dtype %d", (int)dt);
         struct PlanesGuard { PlanesGuard(int p) { set_build_planes(p); } ~PlanesGuard() { set_build_planes(0); } } guard(planes);
@@ -567,7 +571,11 @@ brn_status brn_set_op_compute(int dtype) {
         if (dtype == BRN_F32) g_op_planes = 0;
         else if (dtype == BRN_F32_SPLIT3) g_op_planes = 3;
         else if (dtype == BRN_F32_SPLIT2) g_op_planes = 2;
+#ifdef BRN_DIAG_BUILD
         else if (dtype == BRN_BF16_OPERANDS) g_op_planes = 1;
+#else
+        else if (dtype == BRN_BF16_OPERANDS) fail(BRN_ERR_INVALID_ARG, "compute dtype BRN_BF16_OPERANDS is superseded by BRN_BF16 and only built into libbirefnet_hip_diag.so");
+#endif
         else if (dtype == BRN_BF16) g_op_planes = BUILD_BF16;
         else fail(BRN_ERR_INVALID_ARG, "unsupported compute dtype %d", dtype);
     });
@@ -697,6 +705,15 @@ brn_status brn_window_attention_forward(const float* x, int B, int H, int W, int
         Staging st(stream, loc);
         const float* dx = st.in(x, (size_t)B * H * W * C);
         float* dy = st.out(y, (size_t)B * H * W * C);
+        if (g_op_planes == BUILD_BF16) {
+            // compute mode BRN_BF16 at op level: x is rounded to bf16 at the edge (inside the model LayerNorm writes it as bf16), qkv and
+            // the attention output are bf16 matrices (window_attention_bf16_kernel), y = proj(...) stays fp32 like the residual stream
+            with_arena((hipStream_t)stream, [&](Ctx& c) {
+                float* xb = c.arena->alloc_bytes((size_t)B * H * W * C * 2);
+                if (!c.dry) BRN_HIP(launch_f32_to_bf16(dx, (size_t)B * H * W * C, xb, c.stream));
+                swin_attention(c, bk, xb, B, H, W, C, shift, dy, nullptr, window_size);
+            }, true);
+        } else
         with_arena((hipStream_t)stream, [&](Ctx& c) { swin_attention(c, bk, dx, B, H, W, C, shift, dy, nullptr, window_size); });
         st.finish();
     });
@@ -725,6 +742,30 @@ brn_status brn_patch_merging_forward(const float* x, int B, int H, int W, int C,
             }
             run_gemm(c, red, pm, M2, 4 * C, dy, 2 * C, 0);
         });
+        st.finish();
+    });
+}
+
+brn_status brn_aspp_deformable_forward(const brn_named_tensor* weights, size_t n, const char* prefix, int mode, const float* x, int B,
+                                       int H, int W, float* y, brn_mem loc, int device, void* stream) {
+    return guarded([&] {
+        if (!weights || !x || !y || B < 1 || H < 1 || W < 1) fail(BRN_ERR_INVALID_ARG, "bad argument");
+        if (mode != BRN_DEFORM_REFERENCE_CPU && mode != BRN_DEFORM_DEFORMABLE) fail(BRN_ERR_INVALID_ARG, "unknown deform mode %d", mode);
+        ensure_device(device);
+        DeviceOwner own;
+        OpPlanes op_planes;
+        WeightTable wt(weights, n);
+        ASPPW a;
+        build_aspp_weights(wt, prefix ? prefix : "", mode, own, a);
+        Staging st(stream, loc);
+        const float* dx = st.in(x, (size_t)B * 64 * H * W);
+        float* dy = st.out(y, (size_t)B * 64 * H * W);
+        with_arena((hipStream_t)stream, [&](Ctx& c) {
+            Map T = new_map(c, B, H, W, 64), U = new_map(c, B, H, W, 64);
+            if (!c.dry) BRN_HIP(launch_nchw_to_nhwc(dx, B, 64, H, W, T.p, T.ld, 0, c.stream, c.bf16));
+            aspp_forward(c, a, T, U, mode);
+            if (!c.dry) BRN_HIP(launch_nhwc_to_nchw(U.p, B, 64, H, W, U.ld, 0, dy, c.stream, c.bf16));
+        }, g_op_planes == BUILD_BF16);
         st.finish();
     });
 }

@@ -95,9 +95,18 @@ void run_gemm(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* C, 
     // A already split by its producer (P layout): the LDS-DMA plane kernel (kernels/gemm_planes.hip), when the shape allows
     // (opt-in, BRN_PLANES_KERNEL=1: at batch 1 it measured 10-12 % SLOWER per forward than the warp-specialised kernel in both
     // split modes — MFMA utilisation 0.40 vs 0.44, profiles/r02_pmc_sq_c2_planes.csv — see DESIGN.md 3.1c)
+    // — the kernel lives in the diag build only (make diag), the product library does not carry it)
+#ifdef BRN_DIAG_BUILD
     static const bool planes_on = getenv("BRN_PLANES_KERNEL") && atoi(getenv("BRN_PLANES_KERNEL")) != 0;
     const bool planes_kernel = planes_on && a_planes && gemm_planes_eligible(p);
+#else
+    constexpr bool planes_kernel = false;
+#endif
+#ifdef BRN_DIAG_BUILD
     GemmPlan pl = planes_kernel ? plan_gemm_planes(M, w.N, w.K, w.planes, c_planes != 0) : plan_gemm(M, w.N, w.K, w.wp ? w.planes : 0);
+#else
+    GemmPlan pl = plan_gemm(M, w.N, w.K, w.wp ? w.planes : 0);
+#endif
     if (!planes_kernel && (a_planes || c_planes)) {
         // otherwise P operands exist only on the warp-specialised kernel; a P output cannot go through the split-K reduce pass
         if (!(w.wp && (w.planes == 2 || w.planes == 3))) fail(BRN_ERR_INVALID_ARG, "P activation layout outside the split modes");
@@ -111,8 +120,10 @@ void run_gemm(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* C, 
     const double flop = 2.0 * M * (double)w.N * w.K;
     const double bytes = 4.0 * ((double)M * w.K + (double)w.N * w.K + (double)M * w.N * (R ? 2 : 1));
     Bracket b(c, FAM_GEMM_DENSE, flop, bytes, M, w.N, w.K);
-    if (planes_kernel) BRN_LAUNCH(launch_gemm_planes(p, pl, ws, c.stream));
-    else BRN_LAUNCH(launch_gemm(p, pl, ws, c.stream));
+#ifdef BRN_DIAG_BUILD
+    if (planes_kernel) { BRN_LAUNCH(launch_gemm_planes(p, pl, ws, c.stream)); return; }
+#endif
+    BRN_LAUNCH(launch_gemm(p, pl, ws, c.stream));
 }
 
 // geometry + operands of a deformable conv on kernels/deform_bf16.hip (compute mode BRN_BF16)
@@ -326,7 +337,11 @@ void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int 
             const int np = b0.qkv.planes;
             // (3 planes = rows 1.5x as long: measured 2 % SLOWER per forward in f32_split3 with the warp-specialised kernel, and the
             // LDS-DMA plane kernel, kernels/gemm_planes.hip, which needs P3 input, did not beat it at batch 1: 2 planes only by default)
+#ifdef BRN_DIAG_BUILD
             static const bool planes_on = getenv("BRN_PLANES_KERNEL") && atoi(getenv("BRN_PLANES_KERNEL")) != 0;
+#else
+            constexpr bool planes_on = false;
+#endif
             if (w.window == 12 && (np == 2 || (np == 3 && planes_on)) && b0.qkv.wp && b0.proj.wp && b0.fc1.wp && b0.fc2.wp && C % 32 == 0 && hidden % 32 == 0) stage_pl = np;
         }
         const int ldx = stage_pl ? C * stage_pl / 2 : C, ldh = stage_pl ? hidden * stage_pl / 2 : hidden;
@@ -386,10 +401,19 @@ void swin_forward(Ctx& c, const SwinW& w, const float* img, int B, int H, int W,
 // ---- BasicDecBlk (decoder.rs:126-141) with ASPPDeformable (aspp.rs:303-333) ------------------------------------------------
 void decblk_forward(Ctx& c, const DecBlkW& w, const Map& in, const Map& out, int deform_mode) {
     const size_t mk = c.arena->mark();
-    const int B = in.B, H = in.H, W = in.W, M = B * H * W;
-    Map t = new_map(c, B, H, W, 64);
+    Map t = new_map(c, in.B, in.H, in.W, 64);
     run_conv(c, w.conv_in, in, t);                                   // conv_in + bn_in + relu
-    const ASPPW& a = w.aspp;
+    Map u = new_map(c, in.B, in.H, in.W, 64);
+    aspp_forward(c, w.aspp, t, u, deform_mode);
+    run_conv(c, w.conv_out, u, out);                                 // conv_out + bn_out (no ReLU)
+    c.arena->release(mk);
+}
+
+void aspp_forward(Ctx& c, const ASPPW& a, const Map& t, const Map& u, int deform_mode) {
+    if (t.C != 64 || t.ld != 64 || t.coff || u.C != 64 || u.ld != 64 || u.coff || u.B != t.B || u.H != t.H || u.W != t.W)
+        fail(BRN_ERR_INVALID_ARG, "ASPPDeformable runs on whole 64-channel maps");
+    const size_t mk = c.arena->mark();
+    const int B = t.B, H = t.H, W = t.W, M = B * H * W;
     const int region0 = c.region;
     c.region = REGION_ASPP;
     Map cat = new_map(c, B, H, W, 1024);                             // [aspp1 | deform k1 | k3 | k7]; pooled branch -> bias
@@ -425,10 +449,8 @@ void decblk_forward(Ctx& c, const DecBlkW& w, const Map& in, const Map& out, int
         BRN_LAUNCH(launch_small_fc(g0, B, 64, a.gap_w, 64, 0, 256, a.gap_scale, a.gap_shift, ACT_RELU, g1, c.stream));
         BRN_LAUNCH(launch_small_fc(g1, B, 256, a.conv1_full, 1280, 1024, 64, nullptr, nullptr, ACT_NONE, gb, c.stream));
     }
-    Map u = new_map(c, B, H, W, 64);
     run_gemm(c, a.conv1_main, cat.p, M, 1024, u.p, 64, 0, nullptr, 0, 0, gb, H * W);   // conv1 + bn1 + relu (aspp.rs:329-331)
     c.region = region0;
-    run_conv(c, w.conv_out, u, out);                                 // conv_out + bn_out (no ReLU)
     c.arena->release(mk);
 }
 

@@ -191,6 +191,7 @@ struct Model {
 };
 
 void build_swin_weights(const WeightTable& wt, const std::string& prefix, const brn_config& cfg, DeviceOwner& own, SwinW& out);
+void build_aspp_weights(const WeightTable& wt, const std::string& prefix, int deform_mode, DeviceOwner& own, ASPPW& out);
 void build_decblk_weights(const WeightTable& wt, const std::string& prefix, int cin, int cout, int deform_mode, DeviceOwner& own, DecBlkW& out);
 void build_decoder_weights(const WeightTable& wt, const std::string& prefix, const brn_config& cfg, DeviceOwner& own, DecoderW& out);
 
@@ -229,6 +230,8 @@ void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int 
 void swin_attention(Ctx& c, const SwinBlockW& blk, const float* xn, int B, int H, int W, int C, int shift,
                     float* y, const float* residual, int window = 12);
 void decblk_forward(Ctx& c, const DecBlkW& w, const Map& in, const Map& out, int deform_mode);
+// ASPPDeformable::forward (aspp.rs:303-333) on a 64-channel map t -> 64-channel map u (both whole maps: ld == C == 64)
+void aspp_forward(Ctx& c, const ASPPW& a, const Map& t, const Map& u, int deform_mode);
 void decoder_forward(Ctx& c, const Model& m, const float* img_nchw, int B, int H, int W, const Map& x1, const Map& x2,
                      const Map& x3, const Map& d4 /* [.., 3456] with [0:3072) = squeezed x4 */, float* out, int apply_sigmoid);
 void model_forward(Model& m, Ctx& c, const float* img_nchw, int B, int H, int W, float* out, int apply_sigmoid);

@@ -299,13 +299,17 @@ static GemmW conv_bn(const WeightTable& wt, const std::string& conv, bool has_bi
 
 void build_decblk_weights(const WeightTable& wt, const std::string& p, int cin, int cout, int deform_mode, DeviceOwner& own,
                           DecBlkW& out) {
-    const int IC = 64, PL = 256;   // inter_channels (decoder.rs:96), ASPP planes (aspp.rs:243)
+    const int IC = 64;             // inter_channels (decoder.rs:96)
     out.cin = cin; out.cout = cout;
     if (cin % 32) fail(BRN_ERR_INVALID_ARG, "decoder block in_channels %d must be a multiple of 32", cin);
     out.conv_in = conv_bn(wt, p + "conv_in", true, p + "bn_in", IC, cin, cin, 3, 1, ACT_RELU, own);
     out.conv_out = conv_bn(wt, p + "conv_out", true, p + "bn_out", cout, IC, IC, 3, 1, ACT_NONE, own);   // no ReLU (decoder.rs:138-139)
-    ASPPW& a = out.aspp;
-    const std::string ap = p + "dec_att.";
+    build_aspp_weights(wt, p + "dec_att.", deform_mode, own, out.aspp);
+}
+
+// ASPPDeformable::new (aspp.rs:236-300) for in_channels = 64 under prefix `ap`
+void build_aspp_weights(const WeightTable& wt, const std::string& ap, int deform_mode, DeviceOwner& own, ASPPW& a) {
+    const int IC = 64, PL = 256;   // in / out channels of the module inside BasicDecBlk (decoder.rs:96,107-111), ASPP planes (aspp.rs:243)
     const int ks[4] = {1, 1, 3, 7};
     const std::string mods[4] = {ap + "aspp1.", ap + "aspp_deforms.0.", ap + "aspp_deforms.1.", ap + "aspp_deforms.2."};
     std::vector<float> pair_w, pair_sc, pair_sh;

@@ -1340,7 +1340,15 @@ hipError_t launch_gemm(const GemmParams& p_in, const GemmPlan& pl, float* ws, hi
     if (p.planes > 0 && p.Wp && (p.mode == GEMM_DENSE || p.mode == GEMM_CONV_NHWC)) {
         // split-bf16 path: tile choice by the same plan (64x64 / 128x64 / 128x128 families); the 128x128 tile runs
         // warp-specialised
-        if (pl.cfg == 6 || pl.cfg == 0 || pl.cfg == 3 || pl.cfg == 4 || pl.cfg == 5) e = p.planes == 3 ? launch_split_ws<3>(p, s) : (p.planes == 2 ? launch_split_ws<2>(p, s) : launch_split_ws<1>(p, s));
+        if (pl.cfg == 6 || pl.cfg == 0 || pl.cfg == 3 || pl.cfg == 4 || pl.cfg == 5) {
+            if (p.planes == 3) e = launch_split_ws<3>(p, s);
+            else if (p.planes == 2) e = launch_split_ws<2>(p, s);
+#ifdef BRN_DIAG_BUILD               // one bf16 plane (mode bf16_operands, superseded by the bf16-storage mode): diag build only
+            else e = launch_split_ws<1>(p, s);
+#else
+            else e = hipErrorInvalidValue;
+#endif
+        }
         else if (p.planes == 3) {
             if (pl.cfg == 2) e = launch_split_cfg<64, 64, 2, 2, 3>(p, s);
             else if (pl.cfg == 1) e = launch_split_cfg<128, 64, 2, 2, 3>(p, s);
@@ -1350,9 +1358,13 @@ hipError_t launch_gemm(const GemmParams& p_in, const GemmPlan& pl, float* ws, hi
             else if (pl.cfg == 1) e = launch_split_cfg<128, 64, 2, 2, 2>(p, s);
             else e = launch_split_cfg<128, 128, 2, 2, 2>(p, s);
         } else {
+#ifdef BRN_DIAG_BUILD
             if (pl.cfg == 2) e = launch_split_cfg<64, 64, 2, 2, 1>(p, s);
             else if (pl.cfg == 1) e = launch_split_cfg<128, 64, 2, 2, 1>(p, s);
             else e = launch_split_cfg<128, 128, 2, 2, 1>(p, s);
+#else
+            e = hipErrorInvalidValue;
+#endif
         }
     } else
     if (pl.cfg == 0) e = launch_cfg<128, 128, 2, 2>(p, s);

@@ -650,7 +650,11 @@ hipError_t launch_window_attention2(const WindowAttnParams& p, const WindowAttnP
         if (two_heads && !(p.heads & 1)) hipLaunchKernelGGL(window_attention_bf16_kernel<2>, dim3(n0 + n1, p.heads / 2), dim3(2 * ATT_THREADS), 0, s, p, q, n0);
         else hipLaunchKernelGGL(window_attention_bf16_kernel<1>, grid, block, 0, s, p, q, n0);
     } else if (p.planes == 2) hipLaunchKernelGGL(window_attention_split_kernel<2>, grid, block, 0, s, p, q, n0);
+#ifdef BRN_DIAG_BUILD
     else if (p.planes == 1) hipLaunchKernelGGL(window_attention_split_kernel<1>, grid, block, 0, s, p, q, n0);
+#else
+    else if (p.planes == 1) return hipErrorInvalidValue;      // mode bf16_operands: diag build only
+#endif
     else if (ws == 7) hipLaunchKernelGGL(window_attention_f32_kernel<7>, grid, block, 0, s, p, q, n0);
     else hipLaunchKernelGGL(window_attention_f32_kernel<12>, grid, block, 0, s, p, q, n0);
     return hipGetLastError();

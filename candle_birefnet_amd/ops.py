@@ -3,7 +3,7 @@ Weights are host arrays; activations may be numpy (host) or torch-on-GPU (device
 from . import _ffi
 from . import tensors as T
 
-_COMPUTE = {"f32": _ffi.BRN_F32, "f32_split3": _ffi.BRN_F32_SPLIT3, "f32_split2": _ffi.BRN_F32_SPLIT2, "bf16_operands": _ffi.BRN_BF16_OPERANDS, "bf16": _ffi.BRN_BF16}
+_COMPUTE = {"f32": _ffi.BRN_F32, "f32_split3": _ffi.BRN_F32_SPLIT3, "f32_split2": _ffi.BRN_F32_SPLIT2, "bf16": _ffi.BRN_BF16}
 
 
 def set_compute(mode: str):
@@ -95,4 +95,21 @@ def patch_merging(x, H, W, norm_g, norm_b, reduction_w, device=0):
     y = T.alloc_like(keep, (B, ((H + 1) // 2) * ((W + 1) // 2), 2 * Cc))
     _ffi.check(_ffi.lib.brn_patch_merging_forward(px, B, H, W, Cc, *[h[0] for h in hp], T.ptr_of(y), loc,
                                                   T.device_of(keep, device), T.stream_of(keep)))
+    return y
+
+
+def aspp_deformable(x, tensors, mode="reference_cpu", prefix="", device=0):
+    """ASPPDeformable::forward (aspp.rs:303-333) on a 64-channel NCHW map; `tensors`: name -> host array of the module's weights
+    under `prefix` (SURVEY.md App. A <ASPP>).  mode: "reference_cpu" (aspp.rs:183-185) or "deformable" (aspp.rs:58-165)."""
+    from .birefnet import _named_array
+    B, Cc, H, W = (int(v) for v in x.shape)
+    if Cc != 64:
+        raise ValueError(f"ASPPDeformable inside BasicDecBlk runs on 64 channels, got {Cc}")
+    arr, keep_w = _named_array(tensors)
+    px, loc, keep, _ = T.as_arg(x)
+    y = T.alloc_like(keep, (B, 64, H, W))
+    m = {"reference_cpu": _ffi.BRN_DEFORM_REFERENCE_CPU, "deformable": _ffi.BRN_DEFORM_DEFORMABLE}[mode]
+    _ffi.check(_ffi.lib.brn_aspp_deformable_forward(arr, len(arr), prefix.encode(), m, px, B, H, W, T.ptr_of(y), loc, T.device_of(keep, device),
+                                                    T.stream_of(keep)))
+    del keep_w
     return y

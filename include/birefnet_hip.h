@@ -49,7 +49,8 @@ typedef enum { BRN_MEM_HOST = 0, BRN_MEM_DEVICE = 1 } brn_mem;
  *   BRN_F32_SPLIT3     fp32 operands split error-free into 3 bf16 planes, 6 bf16 MFMAs per product, fp32 accumulate:
  *                      fp32-class accuracy (dropped terms < 2^-24 of a product) at 2.67x the fp32-MFMA rate
  *   BRN_F32_SPLIT2     2 planes, 3 MFMAs: ~2^-16 relative per product
- *   BRN_BF16_OPERANDS  operands rounded to bf16, fp32 accumulate, fp32 storage (parity is informational)
+ *   BRN_BF16_OPERANDS  operands rounded to bf16, fp32 accumulate, fp32 storage: superseded by BRN_BF16; the value is reserved, the
+ *                      product library answers BRN_ERR_INVALID_ARG (only libbirefnet_hip_diag.so, `make diag`, still builds it)
  *   BRN_BF16           the bf16 throughput mode of BASELINE configs[2..4]: activations AND weights live in HBM as bf16,
  *                      bf16 MFMA with fp32 accumulation, fp32 statistics inside LayerNorm / softmax / GAP; x and the logits
  *                      stay fp32 at this boundary.  Parity is informational (error vs the fp32 oracle is reported). */
@@ -216,6 +217,15 @@ brn_status brn_deform_conv2d_forward(const float* x, int B, int C, int H, int W,
                                      const float* mod_w, const float* mod_b,
                                      const float* w, const float* bias, int O, int k, int stride, int pad,
                                      int mode, float* y, brn_mem loc, int device_ordinal, void* stream);
+
+/* ASPPDeformable::new(64, None, &[1, 3, 7]) + forward (aspp.rs:236-333) as BasicDecBlk builds it (decoder.rs:107-111): the five
+ * branches on a 64-channel map (aspp1 and aspp_deforms.{0,1,2} = DeformConvASPP k 1,1,3,7 -> 256, BN, ReLU; global average pool
+ * -> 1x1 -> BN -> ReLU -> broadcast), concat 1280, conv1 1x1 (no bias) + bn1 + ReLU.  weights: the module's tensors under
+ * `prefix` ("aspp1.atrous_conv.offset_conv.weight", ..., "conv1.weight", "bn1.*"; SURVEY.md App. A <ASPP>); mode = brn_deform_mode.
+ * x, y: [B,64,H,W] NCHW. */
+brn_status brn_aspp_deformable_forward(const brn_named_tensor* weights, size_t n_weights, const char* prefix, int mode,
+                                       const float* x, int B, int H, int W, float* y, brn_mem loc,
+                                       int device_ordinal, void* stream);
 
 /* ---- image pre/post-processing: the steps either side of forward_logits in examples/infer_image.rs ------ */
 /* infer_image.rs:44-67.  `img.resize_exact(S, S, FilterType::Triangle)` -> `to_rgb8()` -> (v/255 - mean) / std with the

@@ -797,6 +797,14 @@ int orc_deform_conv2d(const float* x, int B, int C, int H, int W, const float* o
         memcpy(y, t.p(), (size_t)t.numel() * sizeof(float));
     });
 }
+// ASPPDeformable::forward (aspp.rs:303-333) on a 64-channel map; weights under `prefix`
+int orc_aspp(const brn_named_tensor* weights, size_t n, const char* prefix, int mode, const float* x, int B, int H, int W_, float* y) {
+    return guarded([&] {
+        Weights w(weights, n);
+        Tensor t = aspp_deformable(from_ptr(x, {B, 64, H, W_}), w, prefix ? prefix : "", mode);
+        memcpy(y, t.p(), (size_t)t.numel() * sizeof(float));
+    });
+}
 int orc_squeeze(const brn_config* cfg, const brn_named_tensor* weights, size_t n, const float* x4, int B, int h, int w_, float* y) {
     return guarded([&] {
         Weights w(weights, n);

@@ -217,6 +217,16 @@ def deform_conv2d(x, offset_w, offset_b, mod_w, mod_b, w, bias, k, stride, pad, 
     return y
 
 
+def aspp_deformable(x, weights, mode=0, prefix=""):
+    """ASPPDeformable::forward (aspp.rs:303-333): x [B,64,H,W]; mode 0 = reference_cpu, 1 = deformable"""
+    x = _f(x)
+    B, _, H, W = x.shape
+    arr, n, keep = named(weights)
+    y = np.empty((B, 64, H, W), np.float32)
+    _chk(lib().orc_aspp(arr, C.c_size_t(n), prefix.encode(), int(mode), _p(x), B, H, W, _p(y)))
+    return y
+
+
 def squeeze(cfg, weights, x4):
     x4 = _f(x4)
     B, _, h, w = x4.shape

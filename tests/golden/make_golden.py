@@ -45,7 +45,25 @@ def kats():
     for name, (H, W, shift) in {"attn_24_s0": (24, 24, 0), "attn_24_s6": (24, 24, 6), "attn_16_s6": (16, 16, 6), "attn_16_s0": (16, 16, 0)}.items():
         x = torch.from_numpy(rnd(1, H, W, 64, seed=99)).to(D)
         out[name] = R.window_attention_block(x, w, "", 2, 12, shift, D).numpy().astype(np.float32)
-    # roll + partition index map for R=16, ws=12: feed one-hot position codes through the partition (no arithmetic)
+    # SURVEY.md §8(c) KATs of round 3 (ASPP 12x12 in both deform modes, SimpleConvs, GdtConvs, the roll + partition + mask index map for
+    # R = 16 / ws = 12): inputs and weights are defined once, in tests/golden_cases.py; here they run through the fp64 restatement
+    import golden_cases as G
+
+    class TorchBackend:
+        def window_attention(self, x, heads, shift, w):
+            return R.window_attention_block(torch.from_numpy(x).to(D), w, "", heads, 12, shift, D).numpy()
+
+        def aspp(self, x, t, mode):
+            return R.aspp_deformable(torch.from_numpy(x).to(D), t, "", D, "deformable" if mode else "reference_cpu").numpy()
+
+        def simple_convs(self, x, t):
+            return R.simple_convs(torch.from_numpy(x).to(D), t, "", D).numpy()
+
+        def gdt_convs(self, x, t):
+            return torch.nn.functional.relu(R.bn(R.conv(torch.from_numpy(x).to(D), t, "0", D, pad=1), t, "1", D)).numpy()
+
+    for name in ("aspp_12_ref", "aspp_12_def", "simpleconvs_12", "gdtconvs_12", "indexmap_16_s0", "indexmap_16_s6"):
+        out[name] = np.asarray(G.KAT_CASES[name](TorchBackend())).astype(np.float32)
     # patch merging 6x6x32 and an odd 7x5 map
     pw = {"norm.weight": 1 + rnd(128, seed=1, std=0.1), "norm.bias": rnd(128, seed=2, std=0.1), "reduction.weight": rnd(64, 128, seed=3, std=128 ** -0.5)}
     out["pm_6x6"] = R.patch_merging(torch.from_numpy(rnd(1, 36, 32, seed=4)).to(D), 6, 6, pw, "", D).numpy().astype(np.float32)

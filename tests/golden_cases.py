@@ -47,7 +47,47 @@ def _deform(k, mode):
     return run
 
 
+# ---- SURVEY.md §8(c) KATs added in round 3: ASPPDeformable on 12x12 (both deform modes), SimpleConvs, GdtConvs, and the
+# roll + partition + mask INDEX MAP for R = 16 / ws = 12 (trivial arithmetic: every output is a mean of position codes) ----
+def aspp_tensors():
+    from candle_birefnet_amd.weights import _decblk
+    return {n[len("b.dec_att."):]: synth_tensor("kat." + n, s, k, 42) for n, s, k in _decblk("b.", 64, 64) if n.startswith("b.dec_att.")}
+
+
+def _aspp(mode):
+    return lambda be: be.aspp(rnd(1, 64, 12, 12, seed=21), aspp_tensors(), mode)
+
+
+SC_W = {"conv1.weight": rnd(64, 48, 3, 3, seed=31, std=(48 * 9) ** -0.5), "conv1.bias": rnd(64, seed=32, std=0.1),
+        "conv_out.weight": rnd(96, 64, 3, 3, seed=33, std=(64 * 9) ** -0.5), "conv_out.bias": rnd(96, seed=34, std=0.1)}
+GDT_W = {"0.weight": rnd(16, 96, 3, 3, seed=41, std=(96 * 9) ** -0.5), "0.bias": rnd(16, seed=42, std=0.1),
+         "1.weight": 1 + rnd(16, seed=43, std=0.1), "1.bias": rnd(16, seed=44, std=0.1), "1.running_mean": rnd(16, seed=45, std=0.1),
+         "1.running_var": (0.5 + np.random.default_rng(46).random(16)).astype(np.float32)}
+
+
+def indexmap_weights():
+    """q = k = 0 (all scores 0 + mask), v = x, proj = identity, zero bias table: an output token is the MEAN of the input tokens of its
+    window that the SW-MSA mask lets it see (pad tokens count with value 0), so the result shows nothing but the index map of
+    swin.rs:359-401 (pad -> roll -> partition -> mask -> reverse -> roll -> crop)"""
+    C, heads = 64, 2
+    qkv = np.zeros((3 * C, C), np.float32)
+    qkv[2 * C:] = np.eye(C, dtype=np.float32)
+    return {"attn.qkv.weight": qkv, "attn.qkv.bias": np.zeros(3 * C, np.float32), "attn.proj.weight": np.eye(C, dtype=np.float32),
+            "attn.proj.bias": np.zeros(C, np.float32), "attn.relative_position_bias_table": np.zeros((529, heads), np.float32)}
+
+
+def _indexmap(shift):
+    def run(be):
+        i, j, c = np.meshgrid(np.arange(16), np.arange(16), np.arange(64), indexing="ij")
+        x = ((((i * 16 + j) * 37 + c * 11) % 64) / 64.0).astype(np.float32)[None]      # a position code per token and channel
+        return be.window_attention(x, 2, shift, indexmap_weights())
+    return run
+
+
 KAT_CASES = {
+    "aspp_12_ref": _aspp(0), "aspp_12_def": _aspp(1), "simpleconvs_12": lambda be: be.simple_convs(rnd(1, 48, 12, 12, seed=22), SC_W),
+    "gdtconvs_12": lambda be: be.gdt_convs(rnd(1, 96, 12, 12, seed=23), GDT_W),
+    "indexmap_16_s0": _indexmap(0), "indexmap_16_s6": _indexmap(6),
     "attn_24_s0": _attn(24, 24, 0), "attn_24_s6": _attn(24, 24, 6), "attn_16_s6": _attn(16, 16, 6), "attn_16_s0": _attn(16, 16, 0),
     "pm_6x6": _pm(6, 6, 4), "pm_7x5": _pm(7, 5, 5),
     "up_5_9": _up(5, 9), "up_9_5": _up(9, 5), "up_4_4": _up(4, 4),
@@ -94,8 +134,27 @@ class OracleBackend:
                                     t["regular_conv.weight"], t["regular_conv.bias"], k, stride, pad, mode)
 
 
+    def aspp(self, x, t, mode):
+        return self.O.aspp_deformable(x, t, mode)
+
+    def simple_convs(self, x, t):        # decoder.rs:50-56: conv3x3 -> conv3x3, no activation in between
+        return self.O.conv2d(self.O.conv2d(x, t["conv1.weight"], t["conv1.bias"], padding=1), t["conv_out.weight"], t["conv_out.bias"], padding=1)
+
+    def gdt_convs(self, x, t):           # birefnet.rs:111-117: conv3x3 -> BN -> ReLU
+        return self.O.conv2d(x, t["0.weight"], t["0.bias"], padding=1, bn=(t["1.weight"], t["1.bias"], t["1.running_mean"], t["1.running_var"]), act="relu")
+
+
 class HipBackend:
     """adapts the product's C-ABI wrappers (candle_birefnet_amd.ops / DeformableConv2d) to the KAT case signatures"""
+
+    def aspp(self, x, t, mode):
+        return cb.ops.aspp_deformable(x, t, "deformable" if mode else "reference_cpu")
+
+    def simple_convs(self, x, t):
+        return cb.ops.conv2d(cb.ops.conv2d(x, t["conv1.weight"], t["conv1.bias"], padding=1), t["conv_out.weight"], t["conv_out.bias"], padding=1)
+
+    def gdt_convs(self, x, t):
+        return cb.ops.conv2d(x, t["0.weight"], t["0.bias"], padding=1, bn=(t["1.weight"], t["1.bias"], t["1.running_mean"], t["1.running_var"]), act="relu")
 
     def window_attention(self, x, heads, shift, w):
         return cb.ops.window_attention(x, heads, shift, w["attn.qkv.weight"], w["attn.qkv.bias"], w["attn.proj.weight"], w["attn.proj.bias"],

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(HERE)
 GOLD = os.path.join(HERE, "golden")
 # bf16 modes are throughput modes: the fp32 gate (1e-3 abs | 1e-2 rel) does not apply; their error against the fp64 / fp32
 # restatement is REPORTED and bounded here.  |logit| max of the 1024^2 synthetic run is ~2.2.
-BF16_ABS_BOUND = {"bf16_operands": 2e-2, "bf16": 3e-2}   # measured on MI355X: 4.3e-3 / 6.2e-3 (1024^2), 4.4e-3 / 7.2e-3 (2048^2)
+BF16_ABS_BOUND = {"bf16": 2.4e-2}   # 3x the largest error measured on MI355X: 6.4e-3 (1024^2), 7.9e-3 (2048^2, deformable)
 
 
 def _full_model(mode, max_batch=0, size=0):
@@ -25,7 +25,7 @@ def _full_model(mode, max_batch=0, size=0):
     return cb, cb.BiRefNet.new(cfg, cb.VarBuilder.from_tensors(w), compute=mode, max_batch=max_batch, max_size=(size, size))
 
 
-@pytest.mark.parametrize("mode", ["bf16_operands", "bf16"])
+@pytest.mark.parametrize("mode", ["bf16"])
 def test_c3_batch8_1024_bf16(gpu, mode):
     """configs[2] (and one rank of configs[3]): B=8, 1024x1024.  Finite; the same call twice gives the same bits; an image alone
     equals the same image inside the batch up to the mode's rounding; error vs the strided fp64 golden of image 0 is bounded."""
@@ -122,7 +122,7 @@ def test_c5_2048_fp32_equivalent_against_golden(gpu):
     m.close()
 
 
-@pytest.mark.parametrize("mode", ["bf16_operands", "bf16"])
+@pytest.mark.parametrize("mode", ["bf16"])
 def test_c5_batch4_2048_bf16(gpu, mode):
     """configs[4]: B=4, 2048x2048 in the bf16 modes: finite, repeatable, image 0 bounded against the golden, batch independence."""
     import torch

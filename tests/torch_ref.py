@@ -58,8 +58,10 @@ def attn_mask(hp, wp, ws, shift, dtype):  # swin.rs:603-655
     return torch.where(d != 0, torch.full_like(d, -100.0), torch.zeros_like(d))
 
 
-def window_attention_block(xn, w, p, heads, ws, shift, dtype, mask=None):
-    """swin.rs:356-403 + 212-312: xn [B,H,W,C] (norm1 output) -> attention output [B,H,W,C] (before the residual)."""
+def window_attention_block(xn, w, p, heads, ws, shift, dtype, mask=None, store=None):
+    """swin.rs:356-403 + 212-312: xn [B,H,W,C] (norm1 output) -> attention output [B,H,W,C] (before the residual).
+    store: optional rounding applied where the bf16-storage mode keeps a matrix in HBM (the qkv output, the attention output)."""
+    store = store or (lambda t: t)
     B, H, W, C = xn.shape
     pad_r, pad_b = (ws - W % ws) % ws, (ws - H % ws) % ws
     x = F.pad(xn, (0, 0, 0, pad_r, 0, pad_b))
@@ -69,7 +71,7 @@ def window_attention_block(xn, w, p, heads, ws, shift, dtype, mask=None):
     xw = x.reshape(B, hp // ws, ws, wp // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C)
     b_, n, _ = xw.shape
     hd = C // heads
-    qkv = linear(xw, w, p + "attn.qkv", dtype).reshape(b_, n, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    qkv = store(linear(xw, w, p + "attn.qkv", dtype)).reshape(b_, n, 3, heads, hd).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
     q = q * (hd ** -0.5)
     attn = q @ k.transpose(-2, -1)
@@ -84,7 +86,7 @@ def window_attention_block(xn, w, p, heads, ws, shift, dtype, mask=None):
         nW = mask.shape[0]
         attn = (attn.reshape(b_ // nW, nW, heads, n, n) + mask.unsqueeze(0).unsqueeze(2)).reshape(b_, heads, n, n)
     attn = torch.softmax(attn, dim=-1)
-    o = (attn @ v).transpose(1, 2).reshape(b_, n, C)
+    o = store((attn @ v).transpose(1, 2).reshape(b_, n, C))
     o = linear(o, w, p + "attn.proj", dtype)
     o = o.reshape(B, hp // ws, wp // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, hp, wp, C)
     if shift > 0:
