@@ -175,6 +175,49 @@ static void run_model(Model* m, const float* x, int B, int H, int W, brn_mem in_
         for (int i = 0; i < 6; ++i) BRN_HIP(hipEventCreate(&m->stage_ev[i]));
         m->stage_ev_ok = true;
     }
+    // A batch as `parts` sub-batches on `parts` streams (images are independent units): the kernels of one part fill the CUs another
+    // part's launch leaves idle in its last, partial round of tiles, and the write bursts of one part's epilogues fall into the K
+    // loops of the others (measured at batch 8, 1024^2, bf16: +5.6 % with 2 parts).  BRN_SPLIT_STREAMS = number of
+    // parts (default 2; 1 = one stream).  Each part has its own workspace; the results do not depend on how the host interleaves the
+    // enqueues (same kernels, same plans per part, no atomics).  Profiled forwards run on one stream (per-launch events).
+    static const int parts_env = getenv("BRN_SPLIT_STREAMS") ? atoi(getenv("BRN_SPLIT_STREAMS")) : 2;
+    int parts = parts_env < 1 ? 1 : (parts_env > 8 ? 8 : parts_env);
+    if (parts > B / 2) parts = B / 2;                              // at least two images per part
+    if (parts > 1 && !m->profiling && in_loc == BRN_MEM_DEVICE && out_loc == BRN_MEM_DEVICE) {
+        if (!m->fork_ev) BRN_HIP(hipEventCreateWithFlags(&m->fork_ev, hipEventDisableTiming));
+        if ((int)m->sides.size() < parts - 1) m->sides.resize(parts - 1);
+        for (int k = 0; k < parts - 1; ++k) {
+            Model::Side& sd = m->sides[k];
+            if (!sd.stream) {
+                BRN_HIP(hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking));
+                BRN_HIP(hipEventCreateWithFlags(&sd.join_ev, hipEventDisableTiming));
+            }
+            if (!sd.arena.base || sd.arena.cap < m->arena.cap) {
+                if (sd.arena.base) { BRN_HIP(hipDeviceSynchronize()); (void)hipFree(sd.arena.base); sd.arena.base = nullptr; }
+                void* d = nullptr;
+                hipError_t e = hipMalloc(&d, m->arena.cap);
+                if (e != hipSuccess) fail(BRN_ERR_OOM, "workspace hipMalloc of %zu bytes for stream %d failed: %s", m->arena.cap, k + 1, hipGetErrorString(e));
+                sd.arena.base = (char*)d; sd.arena.cap = m->arena.cap;
+            }
+            sd.arena.top = 0; sd.arena.peak = 0; sd.arena.dry = false;
+        }
+        BRN_HIP(hipEventRecord(m->fork_ev, s));
+        int b0 = 0;
+        for (int k = 0; k < parts; ++k) {
+            const int bk = B / parts + (k < B % parts ? 1 : 0);
+            hipStream_t sk = k == 0 ? s : m->sides[k - 1].stream;
+            if (k > 0) BRN_HIP(hipStreamWaitEvent(sk, m->fork_ev, 0));
+            Ctx ck{k == 0 ? &m->arena : &m->sides[k - 1].arena, sk, false, false, nullptr, nullptr, nullptr};
+            ck.bf16 = m->bf16;
+            model_forward(*m, ck, dx + (size_t)b0 * 3 * H * W, bk, H, W, dout + (size_t)b0 * H * W, apply_sigmoid);
+            if (k > 0) BRN_HIP(hipEventRecord(m->sides[k - 1].join_ev, sk));
+            b0 += bk;
+        }
+        for (int k = 1; k < parts; ++k) BRN_HIP(hipStreamWaitEvent(s, m->sides[k - 1].join_ev, 0));
+        BRN_HIP(hipEventRecord(m->done_ev, s));
+        m->last_stream = s; m->has_last = true;
+        return;
+    }
     Ctx c{&m->arena, s, false, m->profiling, &m->records, &m->event_pool, &m->event_next};
     c.bf16 = m->bf16;
     model_forward(*m, c, dx, B, H, W, dout, apply_sigmoid);

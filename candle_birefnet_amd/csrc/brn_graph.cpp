@@ -578,6 +578,12 @@ void model_forward(Model& m, Ctx& c, const float* img, int B, int H, int W, floa
 
 Model::~Model() {
     if (arena.base) (void)hipFree(arena.base);
+    for (Side& sd : sides) {
+        if (sd.arena.base) (void)hipFree(sd.arena.base);
+        if (sd.stream) (void)hipStreamDestroy(sd.stream);
+        if (sd.join_ev) (void)hipEventDestroy(sd.join_ev);
+    }
+    if (fork_ev) (void)hipEventDestroy(fork_ev);
     for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
     if (stage_ev_ok) for (int i = 0; i < 6; ++i) (void)hipEventDestroy(stage_ev[i]);
     if (done_ev) (void)hipEventDestroy(done_ev);

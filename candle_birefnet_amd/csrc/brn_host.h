@@ -180,6 +180,9 @@ struct Model {
     // the workspace is reused by every forward: a call on a different stream than the previous one first waits (on the GPU)
     // for the previous forward's last kernel, so two streams never overlap inside the arena
     hipEvent_t done_ev = nullptr; hipStream_t last_stream = nullptr; bool has_last = false;
+    // two half batches on two streams (run_model): second workspace, side stream, fork / join events
+    struct Side { Arena arena; hipStream_t stream = nullptr; hipEvent_t join_ev = nullptr; };
+    std::vector<Side> sides; hipEvent_t fork_ev = nullptr;
     bool profiling = false;
     bool bf16 = false;        // BRN_BF16: bf16 activations / weights in HBM
     std::vector<LaunchRecord> records;
