@@ -236,7 +236,7 @@ void run_layernorm(Ctx& c, const LNW& ln, const float* x, int rows, int ldx, flo
     LayerNormParams p{};
     p.x = x; p.y = y; p.rows = rows; p.C = ln.C; p.gamma = ln.g; p.beta = ln.b; p.eps = 1e-5f;
     p.ldx = ldx; p.ldy = ldy; p.y_coff = y_coff; p.mode = 0; p.y_planes = y_planes; p.y_bf16 = y_bf16;
-    Bracket b(c, FAM_LAYERNORM, 0.0, (y_bf16 ? 6.0 : 8.0) * rows * (double)ln.C);
+    Bracket b(c, FAM_LAYERNORM, 0.0, (y_bf16 ? 6.0 : 8.0) * rows * (double)ln.C, rows, ln.C, 0);
     BRN_LAUNCH(launch_layernorm(p, c.stream));
 }
 
@@ -379,7 +379,7 @@ void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int 
                     p.x = x + off * C; p.y = c.at(pm, off2 * ldpm); p.rows = M2; p.y_bf16 = yb; p.C = 4 * C; p.gamma = st.down_norm.g; p.beta = st.down_norm.b;
                     p.eps = 1e-5f; p.ldy = ldpm; p.y_coff = 0; p.mode = 1; p.H = hh[k]; p.W = ww[k]; p.Cin = C;
                     p.y_planes = pm_pl;                                            // P layout for the reduction GEMM
-                    Bracket b(c, FAM_LAYERNORM, 0.0, 8.0 * M2 * 4.0 * C);
+                    Bracket b(c, FAM_LAYERNORM, 0.0, 8.0 * M2 * 4.0 * C, M2, 4 * C, 1);
                     BRN_LAUNCH(launch_layernorm(p, c.stream));
                 }
                 off2 += M2;

@@ -1,7 +1,10 @@
 #!/bin/bash
-# A/B one build with / without an environment switch, alternating: tools/ab_env.sh VAR=value [rounds]
-KV=$1; N=${2:-3}
-for i in $(seq $N); do
-  env $KV python bench.py --steps 20 --warmup 5 --cpu-baseline off --also "" --profile-steps 0 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$KV', d['ms_per_step'])"
-  python bench.py --steps 20 --warmup 5 --cpu-baseline off --also "" --profile-steps 0 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('default', d['ms_per_step'])"
+# A/B of an environment switch on one box, alternating: tools/ab_env.sh VAR "0 1" "c3 c5" [extra bench args]
+VAR=$1; VALS=$2; CFGS=$3; shift 3
+for i in 1 2; do
+  for cfg in $CFGS; do
+    for v in $VALS; do
+      env $VAR=$v python bench.py --config $cfg --cpu-baseline off --profile-steps 0 --other-configs off --steps 20 "$@" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$cfg $VAR=$v', d['value'], d['ms_per_step'], d['max_abs_err_image0_vs_strided_golden'])"
+    done
+  done
 done
