@@ -160,3 +160,25 @@ def test_two_processes_two_handles_bit_equal(gpu, tmp_path, compute):
     y1 = np.concatenate([m.forward_logits(x[0:2]), m.forward_logits(x[2:3])], 0)
     np.testing.assert_array_equal(ys, y1)
     m.close()
+
+
+def test_bench_two_ranks_reports_c4_blocks(gpu):
+    """configs[3] (B = 64 over 8 GPUs = 8 images per rank) through bench.py's own N > 1 path, rehearsed with 2 ranks that share this
+    box's one card (gloo for the control plane: RCCL refuses two ranks on one device; the rates of such a run mean nothing): the
+    self-launcher, the rendezvous, shard_range, per-rank times, and the c4 / c4_deformable blocks of the default line."""
+    import json
+    import subprocess
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--cpu-baseline", "off"],
+                        env=dict(os.environ, BRN_BENCH_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    lines = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 prints ONE JSON line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 2 and len(d["per_rank_ms_per_step"]) == 2
+    assert d["outputs_finite"] and d["max_abs_err_image0_vs_strided_golden"] < 2e-4
+    assert sorted(d["other_configs"]) == ["c4", "c4_deformable"]
+    for k, blk in d["other_configs"].items():
+        assert blk["n_gpus"] == 2 and blk["batch_per_gpu"] == 8 and blk["compute"] == "bf16" and len(blk["per_rank_ms_per_step"]) == 2
+        assert blk["outputs_finite"] and blk["max_abs_err_image0_vs_strided_golden"] < BF16_ABS_BOUND["bf16"]
+        assert blk["deform_mode"] == ("deformable" if k.endswith("deformable") else "reference_cpu")
+        assert blk["roofline"]["families"]["gemm_deform_nhwc"]["launches"] == (20 if k.endswith("deformable") else 0)
