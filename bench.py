@@ -140,6 +140,16 @@ def launch_ranks(n, cmd, extra_env=None, timeout=None):
     return rc
 
 
+def streams_used(batch):
+    """sub-batches = HIP streams the library runs a device-resident batch of this size on (brn_api.cpp run_model: BRN_SPLIT_STREAMS,
+    default 2, at least two images per part; profiled forwards always run on one stream)"""
+    try:
+        want = int(os.environ.get("BRN_SPLIT_STREAMS", "2"))
+    except ValueError:
+        want = 2
+    return max(1, min(max(1, min(want, 8)), batch // 2))
+
+
 def golden_error(y, S, deform_mode):
     """max |y[0] - golden| on the committed strided golden of image 0 (seed 1000) for this geometry and deform mode
     (tests/golden/make_golden.py: fp64 torch restatement at 1024^2, fp32 at 2048^2), or None when there is none"""
@@ -206,7 +216,8 @@ def roofline_block(fam, n, compute, traffic_key, quote_traffic):
         "launches_per_step": launches // n, "gflop_per_step": round(fl / n / 1e9, 1), "ms_per_step": round(ms / n, 3),
         "avg_launch_ms": round(ms / max(1, launches), 4),
         "algorithmic_gbytes_per_step": round(by / n / 1e9, 2),
-        "measured_over": f"{n} profiled step(s) after the timed region (HIP events bracketing every launch)",
+        "measured_over": f"{n} profiled step(s) after the timed region (HIP events bracketing every launch; the whole batch on ONE stream, "
+                         "also where the timed region runs it as sub-batches on several streams: kernel durations of kernels running alone)",
         "families": {k: {"launches": v["launches"] // n, "ms": round(v["ms"] / n, 3), "gflop": round(v["gflop"] / n, 1),
                          "gbytes": round(v["gbytes"] / n, 3)}
                      for k, v in fam.items() if not k.startswith("region_")},
@@ -426,6 +437,7 @@ def main(argv=None):
                 blk = {"workload": olabel + (f"; that per-GPU workload on each of {world} ranks" if world > 1 else ""),
                        "images_per_s": round(ips, 3), "ms_per_step": round(t_o / OTHER_STEPS * 1e3, 3), "steps": OTHER_STEPS, "warmup": OTHER_WARMUP,
                        "n_gpus": world, "batch_per_gpu": oB, "size": oS, "dtype": MODES[omode][1], "compute": omode, "deform_mode": dm,
+                       "streams_per_gpu": streams_used(oB),
                        "outputs_finite": bool(torch.isfinite(y_o).all().item()),
                        "reference_gflop_per_image": round(g_ref, 1),
                        "whole_step_frac_of_mode_peak": round(ips / world * g_ref / 1e3 / PEAK_BF16_MFMA_TFLOPS, 4),
@@ -454,7 +466,7 @@ def main(argv=None):
             "vs_baseline": None, "dtype": MODES[compute][1], "data": "synthetic",
             "config": {"workload": workload, "baseline_config": None if custom else args.config,
                        "batch_per_gpu": B, "global_batch": B * world, "size": S, "deform_mode": args.deform_mode,
-                       "compute": compute,
+                       "compute": compute, "streams_per_gpu": streams_used(B),
                        "parallelism": f"{world} replica(s), batch-sharded (candle_birefnet_amd.shard.shard_range), no data-path collective",
                        "inputs": "resident in HBM (torch cuda tensors), weights: synthetic seed 42"},
             "outputs_finite": finite,
