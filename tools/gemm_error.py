@@ -10,7 +10,7 @@ for (M, N, K) in [(5120, 3072, 768), (640, 256, 768), (5120, 768, 3072)]:
     w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
     b = rng.standard_normal(N).astype(np.float32)
     ref = x.astype(np.float64) @ w.astype(np.float64).T + b
-    for mode in ("f32", "f32_split3", "f32_split2", "bf16_operands"):
+    for mode in ("f32", "f32_split3", "f32_split2", "bf16"):
         ops.set_compute(mode)
         y = ops.linear(torch.from_numpy(x).cuda(), w, b).cpu().numpy().astype(np.float64)
         e = np.abs(y - ref)

@@ -9,7 +9,7 @@ ref = k["m1024_full_ref_s16"].astype(np.float64)
 cfg = cb.BiRefNetConfig()
 w = cb.synth_weights(cb.birefnet_weight_spec(cfg), seed=42)
 x = torch.from_numpy(cb.synth_input(1, 1024, 1024)).cuda()
-for mode in sys.argv[1:] or ["f32", "f32_split3", "f32_split2", "bf16_operands"]:
+for mode in sys.argv[1:] or ["f32", "f32_split3", "f32_split2", "bf16"]:
     m = cb.BiRefNet.new(cfg, cb.VarBuilder.from_tensors(w), max_batch=1, max_size=(1024, 1024), compute=mode)
     for _ in range(3): y = m.forward_logits(x)
     torch.cuda.synchronize(); t = time.perf_counter()
