@@ -5,6 +5,7 @@
 #![cfg(feature = "hip")]
 
 pub mod hip_ffi;
+pub mod aspp;
 pub mod birefnet;
 pub mod deform_conv;
 pub mod swin;

@@ -112,6 +112,26 @@ def main():
         args = [a.strip() for a in " ".join(m.group(1).split()).split(",")]
         if "device" not in args or not any(a.startswith("max_batch") for a in args):
             errs.append(f"a brn_model_create call site does not pass the caller's device / max_batch: {args}")
+    # rust_shim/src/aspp.rs walks the same names as the Python mirror's <ASPP> spec (candle_birefnet_amd/weights.py::_decblk)
+    sys.path.insert(0, ROOT)
+    from candle_birefnet_amd.weights import _decblk
+    want = sorted(n[len("b.dec_att."):] for n, _, _ in _decblk("b.", 64, 64) if n.startswith("b.dec_att."))
+    a = open(os.path.join(ROOT, "rust_shim", "src", "aspp.rs")).read()
+    got = []
+    for module, k in (("aspp1", 1), ("aspp_deforms.0", 1), ("aspp_deforms.1", 3), ("aspp_deforms.2", 7)):
+        if f'("{module}", {k}' not in a.replace("usize", ""):
+            errs.append(f"aspp.rs: module {module} (k {k}) missing from aspp_weight_spec")
+        for leaf in ("offset_conv.weight", "offset_conv.bias", "modulator_conv.weight", "modulator_conv.bias", "regular_conv.weight"):
+            if leaf not in a:
+                errs.append(f"aspp.rs: {leaf} missing")
+            got.append(f"{module}.atrous_conv.{leaf}")
+        got += [f"{module}.bn.{l}" for l in ("weight", "bias", "running_mean", "running_var")]
+    got += ["global_avg_pool.1.weight", "conv1.weight"] + [f"{p}.{l}" for p in ("global_avg_pool.2", "bn1") for l in ("weight", "bias", "running_mean", "running_var")]
+    for lit in ('"global_avg_pool.1.weight"', '"conv1.weight"', '"global_avg_pool.2"', '"bn1"'):
+        if lit not in a:
+            errs.append(f"aspp.rs: {lit} missing")
+    if sorted(got) != want:
+        errs.append("aspp.rs: the name list differs from the Python mirror's <ASPP> spec")
     for e in errs:
         print("MISMATCH:", e)
     print(f"{len(hf)} header entry points, {len(rf)} in hip_ffi.rs, {len(errs)} problem(s)")
