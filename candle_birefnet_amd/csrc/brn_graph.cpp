@@ -67,6 +67,18 @@ static void run_gemm_bf16(Ctx& c, const GemmW& w, GemmParams& p, int fam) {
     c.arena->release(mk);
     if (c.dry) return;
     p.Wp = w.wb; p.wp_rows = w.wb_rows; p.wp_ld = w.wb_ld; p.planes = 1;
+    static const bool wstat_off = getenv("BRN_WSTAT") && atoi(getenv("BRN_WSTAT")) == 0;
+    if (w.wf && w.mode == GEMM_DENSE && !wstat_off) {          // short K, wide A: the weights stay in registers (gemm_wstat_bf16_kernel)
+        GemmParams q = p;
+        q.Wp = w.wf;
+        if (gemm_wstat_eligible(q)) {
+            const double flop_ = 2.0 * q.M * (double)q.N * q.K;
+            const double bytes_ = 2.0 * ((double)q.M * q.K + (double)q.N * q.K + (double)q.M * q.N);
+            Bracket b(c, fam, flop_, bytes_, q.M, q.N, q.K);
+            BRN_LAUNCH(launch_gemm_wstat(q, c.stream));
+            return;
+        }
+    }
     const double flop = 2.0 * p.M * (double)p.N * p.K;
     const double a_elems = p.mode == GEMM_DENSE ? (double)p.M * p.K : (double)p.M / ((double)p.Hout * p.Wout) * p.Hin * p.Win * p.Cin;
     const double bytes = 2.0 * (a_elems + (double)p.N * p.K) + (p.c_f32 ? 4.0 : 2.0) * (double)p.M * p.N + (p.R ? (p.r_f32 ? 4.0 : 2.0) * (double)p.M * p.N : 0.0);

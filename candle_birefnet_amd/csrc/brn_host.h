@@ -219,6 +219,8 @@ void run_conv(Ctx& c, const GemmW& w, const Map& in, const Map& out, const float
 bool deform_fused_sigmoid(const Ctx& c, const GemmW& w);
 // bf16-storage mode: attach the fragment-ordered copy of a channels-last conv weight (w: candle [O][Cin][kh][kw]) for deform_bf16
 void attach_deform_frags(DeviceOwner& own, GemmW& g, const float* w_oihw);
+// bf16-storage mode: the fragment-ordered copy of a Linear's [N][K] weight for gemm_wstat_bf16_kernel (K = 192, N % 192 == 0 only)
+void attach_dense_frags(DeviceOwner& own, GemmW& g, const float* w);
 void run_conv_nchw(Ctx& c, const GemmW& w, const float* x_nchw, int B, int Hin, int Win, const Map& out, bool pad_to_stride = false);
 void run_layernorm(Ctx& c, const LNW& ln, const float* x, int rows, int ldx, float* y, int ldy, int y_coff, int y_planes = 0, int y_bf16 = 0);
 void run_resize(Ctx& c, const Map& in, const Map& out);

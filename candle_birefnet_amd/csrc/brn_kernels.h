@@ -60,6 +60,11 @@ hipError_t launch_gemm(const GemmParams& p, const GemmPlan& plan, float* ws, hip
 GemmPlan plan_gemm_bf16(int M, int N, int K, bool f32_residual = false, bool gelu = false);   // f32_residual: fp32 C with an fp32 residual (proj / fc2)
 hipError_t launch_gemm_bf16(const GemmParams& p, const GemmPlan& plan, float* ws, hipStream_t s);
 
+// bf16-storage mode, short-K dense GEMM with the weights resident in registers (kernels/gemm_bf16.hip, gemm_wstat_bf16_kernel): Wp = the weights in
+// MFMA fragment order (GemmW::wf, attach_dense_frags), K = 192, N % 192 == 0, bf16 out, bias + activation only
+bool gemm_wstat_eligible(const GemmParams& p);
+hipError_t launch_gemm_wstat(const GemmParams& p, hipStream_t s);
+
 // bf16-storage mode, modulated deformable conv (kernels/deform_bf16.hip): A = bf16 channels-last map, om = fp32 offsets | modulator,
 // Wp = the weights in MFMA fragment order (GemmW::wf), C = bf16 window.  eligible(): shapes the kernel covers (else gemm_f32_kernel)
 bool deform_bf16_eligible(const GemmParams& p);

@@ -134,6 +134,7 @@ GemmW make_linear(DeviceOwner& own, const float* w, const float* bias, int N, in
     memcpy(pk.data(), w, (size_t)N * K * sizeof(float));
     g.w = own.upload(pk);
     attach_planes(own, g, pk, roundup(N, 128));
+    attach_dense_frags(own, g, w);
     if (bias) g.bias = own.upload(bias, N);
     return g;
 }
@@ -153,6 +154,7 @@ GemmW make_conv_nhwc(DeviceOwner& own, const float* w, const float* bias, int O,
                     pk[(size_t)o * g.K + (size_t)(ky * kw + kx) * cinp + ci] = w[(((size_t)o * Cin + ci) * kh + ky) * kw + kx];
     g.w = own.upload(pk);
     attach_planes(own, g, pk, roundup(O, 128));
+    if (g.mode == GEMM_DENSE && cinp == Cin) attach_dense_frags(own, g, w);      // 1x1 conv = Linear: [O][Cin] as stored
     if (bias) g.bias = own.upload(bias, O);
     return g;
 }
@@ -171,6 +173,23 @@ void attach_deform_frags(DeviceOwner& own, GemmW& g, const float* w) {
                 const int kt = k >> 6, s = (k >> 5) & 1, lane = ((k >> 3) & 3) * 16 + (n & 15), e = k & 7;
                 wf[((((size_t)(n >> 4) * nk + kt) * 2 + s) * 64 + lane) * 8 + e] = bf16_rne(w[((size_t)n * g.Cin + ci) * kk + t]);
             }
+    void* d = nullptr;
+    hipError_t e = hipMalloc(&d, wf.size() * 2 + 16);
+    if (e != hipSuccess) fail(BRN_ERR_OOM, "hipMalloc of %zu bytes failed: %s", wf.size() * 2, hipGetErrorString(e));
+    own.ptrs.push_back(d);
+    BRN_HIP(hipMemcpy(d, wf.data(), wf.size() * 2, hipMemcpyHostToDevice));
+    g.wf = d;
+}
+
+void attach_dense_frags(DeviceOwner& own, GemmW& g, const float* w) {
+    if (g_build_planes != BUILD_BF16 || g.mode != GEMM_DENSE || g.K != 192 || g.N < 192 || g.N % 192) return;
+    const int k32 = g.K / 32, nb_n = g.N / 16;
+    std::vector<uint16_t> wf((size_t)nb_n * k32 * 64 * 8, 0);
+    for (int n = 0; n < g.N; ++n)
+        for (int k = 0; k < g.K; ++k) {
+            const int lane = ((k >> 3) & 3) * 16 + (n & 15);
+            wf[(((size_t)(n >> 4) * k32 + (k >> 5)) * 64 + lane) * 8 + (k & 7)] = bf16_rne(w[(size_t)n * g.K + k]);
+        }
     void* d = nullptr;
     hipError_t e = hipMalloc(&d, wf.size() * 2 + 16);
     if (e != hipSuccess) fail(BRN_ERR_OOM, "hipMalloc of %zu bytes failed: %s", wf.size() * 2, hipGetErrorString(e));

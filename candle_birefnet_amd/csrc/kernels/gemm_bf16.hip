@@ -673,6 +673,149 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
     }
 }
 
+
+// =====================================================================================================================
+// gemm_wstat_bf16_kernel — dense C = act(A W^T + b) for SHORT K (K = 64 KS <= 192) and wide A (M >> N): the stage-0 qkv / fc1 GEMMs of
+// the Swin backbone at batch >= 4 (swin.rs:98,130; M = 655 360, K = 192, N = 576 / 768 at batch 8).  With three K steps per tile the
+// persistent 256 x 256 kernel above is prologue / epilogue all the way (2.0 - 2.6 TB/s of algorithmic traffic); here the weights never
+// move: a wave keeps its 48 columns of W (K x 48 bf16 = 72 VGPRs, loaded once, stored in MFMA fragment order by attach_dense_frags) for
+// the whole launch and the workgroup streams 64-row tiles of A through a two-buffer LDS ring (LDS-DMA, XOR-swizzled 128-byte rows as
+// above); what is left per tile is 24 KB in, 96 MFMAs per wave, 24 KB out.  A workgroup = 4 waves = 192 columns; the N / 192 column
+// groups of a row tile are neighbouring workgroups of one XCD walking the same tiles (the A tile is read from HBM once, then from L2).
+// The C tile goes back through the A buffer it came from (two 32-row halves, 512-byte rows, XOR-ed chunks) and leaves as 384-byte
+// row segments.
+// =====================================================================================================================
+__device__ __forceinline__ int ws_slot(int r, int c) { return (r >> 1) * 256 + (((((r & 1) << 3) | c) ^ ((r >> 1) & 15)) << 4); }
+
+template <int KS, int ACT>
+__global__ void __launch_bounds__(256, 2) gemm_wstat_bf16_kernel(const GemmParams p) {
+    constexpr int WBM = 64, WBN = 192, SUB = WBM * 128;                 // rows per tile, columns per workgroup, bytes of one K step's sub-tile
+    constexpr int K32 = KS * 2, ABUF = KS * SUB;
+    static_assert(ABUF >= 32 * 512, "a 32-row half of the C tile (512-byte rows) must fit the A buffer it replaces");
+    __shared__ __attribute__((aligned(1024))) char smem[2 * ABUF];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = p.N / WBN, T = (p.M + WBM - 1) / WBM;
+    // workgroups of one XCD (same blockIdx % 8): local index li -> column group li % G, walker li / G of nw; XCD x owns a contiguous run of row tiles
+    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3, nw = ((int)gridDim.x >> 3) / G;
+    const int grp = li % G, wk = li / G;
+    const int t_lo = (int)((long)T * xcd / 8), t_hi = (int)((long)T * (xcd + 1) / 8);
+    if (wk >= nw) return;
+    const int n0 = grp * WBN + wave * 48;                               // this wave's first column
+    // ---- W fragments, resident for the whole launch ----
+    bf16x8 wfr[3][K32];
+    {
+        const char* wf = reinterpret_cast<const char*>(p.Wp) + ((long)(n0 >> 4) * K32 * 64 + lane) * 16;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int ks = 0; ks < K32; ++ks) wfr[j][ks] = *reinterpret_cast<const bf16x8*>(wf + (long)(j * K32 + ks) * 1024);
+    }
+    f32x4_b bias[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) bias[j] = p.bias ? *reinterpret_cast<const f32x4_b*>(p.bias + n0 + 16 * j + 4 * (lane >> 4)) : zero4b();
+    // ---- this lane's share of an A tile: LDS-DMA instruction ii = wave + 4 j (j = 0, 1) of every sub-tile fills bank rows 4 ii .. 4 ii + 3 ----
+    unsigned a_voff[2];
+    int a_row[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pr = 4 * (wave + 4 * j) + (lane >> 4), qs = (lane & 15) ^ (pr & 15);
+        a_row[j] = 2 * pr + (qs >> 3);
+        a_voff[j] = (unsigned)((qs & 7) * 16);                          // byte offset inside the 128-byte K-step piece of the row
+    }
+    const __bf16* Ab = reinterpret_cast<const __bf16*>(p.A);
+    auto issue = [&](int t, char* buf) {
+        const int m0 = t * WBM;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Ab + (long)m0 * p.lda + p.a_coff), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned ro = (unsigned)((min(m0 + a_row[j], p.M - 1) - m0) * p.lda * 2) + a_voff[j];   // rows >= M re-read row M - 1 (never stored)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) blds16(rs, ro, ks * 128, buf + ks * SUB + (wave + 4 * j) * 1024);
+        }
+    };
+    int a_foff[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) a_foff[i][s2] = ws_slot(16 * i + (lane & 15), 4 * s2 + (lane >> 4));
+
+    int t = t_lo + wk;
+    if (t < t_hi) issue(t, smem);
+    for (int it = 0; t < t_hi; ++it, t += nw) {
+        char* buf = smem + (it & 1) * ABUF;
+        const bool more = t + nw < t_hi;
+        if (more) { issue(t + nw, smem + ((it + 1) & 1) * ABUF); wait_vmcnt<2 * KS>(); }   // this tile (and the previous tile's stores) landed; the next one may be in flight
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        f32x4_b acc[4][3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[i][j] = zero4b();
+#pragma unroll
+        for (int ks = 0; ks < K32; ++ks) {
+            bf16x8 af[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(buf + (ks >> 1) * SUB + a_foff[i][ks & 1]);
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[j][ks], af[i], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                   // every wave has read its fragments: the buffer now takes the C tile
+        const int m0 = t * WBM;
+        __bf16* Cb = reinterpret_cast<__bf16*>(p.C);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = 2 * half + ii, row = 16 * ii + (lane & 15);          // row within the 32-row half
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    f32x4_b v = acc[i][j] + bias[j];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (ACT == ACT_GELU_ERF) v[e] = gelu_erf_bf16out(v[e]);
+                        else if (ACT == ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    const int col = wave * 48 + 16 * j + 4 * (lane >> 4);           // column within the workgroup's 192
+                    const u32x2_b o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    *reinterpret_cast<u32x2_b*>(buf + row * 512 + (((col >> 3) ^ (row & 31)) << 4) + (col & 4) * 2) = o;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {                                // 32 rows x 24 chunks of 16 bytes over 256 threads
+                const int idx = tid + 256 * q, row = idx / 24, ch = idx - row * 24;
+                const u32x4_b v = *reinterpret_cast<const u32x4_b*>(buf + row * 512 + ((ch ^ (row & 31)) << 4));
+                const int m = m0 + half * 32 + row;
+                if (m < p.M) *reinterpret_cast<u32x4_b*>(Cb + (long)m * p.ldc + p.c_coff + grp * WBN + ch * 8) = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                               // the half (and, after the second one, the buffer) is free again
+        }
+    }
+}
+
+constexpr int WSTAT_WG_PER_CU = 2;      // 2: <= 256 VGPRs, no spill (forced to 168 for three per CU the kernel spills 30-40 registers)
+bool gemm_wstat_eligible(const GemmParams& p) {
+    return p.mode == GEMM_DENSE && p.Wp && (p.K == 192) && p.N >= 192 && (p.N % 192) == 0 && !p.c_f32 && !p.R && !p.scale && !p.bbias &&
+           ((p.lda | p.a_coff | p.ldc | p.c_coff) & 7) == 0 && p.M >= 32768 && (long)p.lda * 2 * 64 < 0x7fffffffL;
+}
+hipError_t launch_gemm_wstat(const GemmParams& p, hipStream_t s) {
+    if (!gemm_wstat_eligible(p)) return hipErrorInvalidValue;
+    const int G = p.N / 192;
+    const int nw = (256 * WSTAT_WG_PER_CU / 8) / G;
+    dim3 grid(8 * G * nw), block(256);
+    if (p.act == ACT_GELU_ERF) hipLaunchKernelGGL((gemm_wstat_bf16_kernel<3, ACT_GELU_ERF>), grid, block, 0, s, p);
+    else if (p.act == ACT_RELU) hipLaunchKernelGGL((gemm_wstat_bf16_kernel<3, ACT_RELU>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_wstat_bf16_kernel<3, ACT_NONE>), grid, block, 0, s, p);
+    return hipGetLastError();
+}
+
 // split-K second pass for the bf16 mode: fixed-order sum of the fp32 slices + the epilogue, bf16 (or fp32) out
 __global__ void splitk_reduce_bf16_kernel(const GemmParams p) {
     const long total = (long)p.M * p.N;

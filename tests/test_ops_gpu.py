@@ -384,6 +384,27 @@ def test_window_attention_bf16_two_heads_per_workgroup(gpu, tmp_path):
         np.testing.assert_array_equal(res["1"][k], res["2"][k])
 
 
+@pytest.mark.parametrize("H,W,O,act", [(192, 192, 576, None), (181, 183, 768, "gelu_erf"), (192, 171, 192, "relu"), (256, 256, 1152, "gelu_erf")])
+def test_short_k_weight_stationary_gemm_bf16_mode(gpu, H, W, O, act):
+    """gemm_wstat_bf16_kernel (K = 192, N % 192 == 0, M >= 32768: the stage-0 qkv / fc1 GEMMs at batch >= 4) through a 1x1 conv on a
+    bf16 map: full and ragged row tiles (M % 64 != 0), 1 / 3 / 4 / 6 column groups, bias, GELU / ReLU.  Exact-operand reference;
+    the output map is bf16: one bf16 ulp (+ the 3-term erfc's 2.6e-5 for GELU)."""
+    from candle_birefnet_amd import ops
+    C = 192
+    x, w, b = rnd(1, C, H, W, seed=1), rnd(O, C, 1, 1, seed=2, std=C ** -0.5), rnd(O, seed=3, std=0.1)
+    ops.set_compute("bf16")
+    try:
+        y = ops.conv2d(x, w, b, act=act)
+        y2 = ops.conv2d(x, w, b, act=act)
+    finally:
+        ops.set_compute("f32")
+    np.testing.assert_array_equal(y, y2)
+    ref = F.conv2d(torch.from_numpy(_bf16_round(x)), torch.from_numpy(_bf16_round(w)), torch.from_numpy(b).double())
+    ref = (F.gelu(ref) if act == "gelu_erf" else F.relu(ref) if act == "relu" else ref).numpy()
+    err = np.abs(np.asarray(y, np.float64) - ref)
+    assert (err <= 2.0 ** -8 * np.abs(ref) + 4e-5).all(), f"max abs err {err.max():.3e}"
+
+
 def test_conv2d_nan_stays_local(gpu):
     """masked (zero-padded) taps are zeroed by a bit mask / zero page, not by 0 * x: a non-finite input pixel spreads
     only over its receptive field, like candle's conv2d; before, Inf at pixel (0,0) turned every border output into NaN."""
