@@ -254,6 +254,20 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_f32_kernel(const GemmParams 
                 const long off = ok ? a_base[i] + ((long)iy * p.Win + ix) * p.lda + ci0 : (long)p.a_coff;
                 ra[i] = load4_masked(p.A + off + kq * 4, ok, am[i]);
             }
+        } else if (MODE == GEMM_GATHER_NCHW && p.kw == 4 && p.stride == 4 && p.pad == 0 && p.dil == 1 && (p.Win & 3) == 0 && (reinterpret_cast<unsigned long long>(p.A) & 15) == 0) {
+            // PatchEmbed (swin.rs:677: k 4, s 4, no padding) on an image whose width is a multiple of 4: a lane's four k indices
+            // k4 .. k4 + 3 are the four kx of one (channel, ky) = 16 contiguous bytes of the image: one unpredicated float4 load from a
+            // clamped address + the bit mask (the per-element form below costs 4 predicated scalar loads and 4 index divisions)
+            const int k4 = k0 + kq * 4, khw = p.kh * 4;
+            const int c = k4 / khw, ky = (k4 - c * khw) >> 2;
+            const bool kin = k4 < p.Kreal;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                const int iy = a_iy[i] + ky;
+                const bool ok = a_ok[i] && kin && iy < p.Hin;              // (bottom rows of a height that is not a multiple of 4 are zero padding)
+                const long off = ok ? a_base[i] + ((long)c * p.Hin + iy) * p.Win + a_ix[i] : 0;
+                ra[i] = load4_masked(p.A + off, ok, am[i]);
+            }
         } else if (MODE == GEMM_GATHER_NCHW) {
             const int khw = p.kh * p.kw;
 #pragma unroll
