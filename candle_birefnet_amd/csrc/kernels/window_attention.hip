@@ -479,15 +479,43 @@ __global__ void __launch_bounds__(ATT_BF16_HPW * ATT_THREADS) __attribute__((amd
         if (sw >= p.Wp) sw -= p.Wp;
         return (sh < p.H && sw < p.W) ? (b * p.H + sh) * p.W + sw : -1;
     };
-    // ---- this wave's three Q fragments first: their latency hides behind the K / V staging ----
+    // ---- every global load of the workgroup goes out FIRST, unconditionally, from clamped addresses (a pad token reads row 0 and is
+    // fixed up afterwards): the three Q fragments, the head's bias table, the K / V rows.  The first version loaded under lane-dependent
+    // branches and in two dependent loops — hipcc waits vmcnt(0) at every join — and paid five HBM round trips one after the other
+    // (3 table iterations, 2 staging iterations) in a kernel whose lifetime is little more than its memory latency. ----
+    constexpr int NTHR = ATT_BF16_HPW * ATT_THREADS;
+    constexpr int NITEM = (NTOK / 2) * 4 * ATT_BF16_HPW;                // (token pair, head of the pair, 8-wide d chunk)
+    constexpr int NTAB = ATT_BF16_HPW * TABN;
+    static_assert(2 * NTHR >= NITEM && 3 * NTHR >= NTAB, "two staging items and three table words per thread cover a head group");
     bf16x8 qf[3];
     int qsrc_[3];
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
         const int qs = tok_src((wv + 3 * u) * 16 + li);
         qsrc_[u] = qs;
-        if (qs >= 0) qf[u] = *reinterpret_cast<const bf16x8*>(qkv + (long)qs * C3 + head * HD + g * 8);
-        else qf[u] = bias8_bf16(p.qkv_bias + head * HD + g * 8);
+        qf[u] = *reinterpret_cast<const bf16x8*>(qkv + (long)max(qs, 0) * C3 + head * HD + g * 8);
+    }
+    float tbw[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int i = min(tid + j * NTHR, NTAB - 1), hh = i / TABN, jj = i - hh * TABN;
+        tbw[j] = p.rel_table[(blockIdx.y * ATT_BF16_HPW + hh) * TABN + (TABN - 1 - jj)];
+    }
+    bf16x8 kv[2][2], vv[2][2];
+    int ssrc[2][2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = min(tid + it * NTHR, NITEM - 1);
+        const int c8 = (idx & 3) * 8, hh = (idx >> 2) & (ATT_BF16_HPW - 1), tp = idx / (4 * ATT_BF16_HPW);
+        const int hd = (blockIdx.y * ATT_BF16_HPW + hh) * HD;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int src = tok_src(tp * 2 + u);
+            ssrc[it][u] = src;
+            const __bf16* kp = qkv + (long)max(src, 0) * C3 + C + hd + c8;
+            kv[it][u] = *reinterpret_cast<const bf16x8*>(kp);
+            vv[it][u] = *reinterpret_cast<const bf16x8*>(kp + C);
+        }
     }
     if (tid < NTOK) {
         const int ti = tid / WS, tj = tid - ti * WS;
@@ -496,39 +524,40 @@ __global__ void __launch_bounds__(ATT_BF16_HPW * ATT_THREADS) __attribute__((amd
         const int fw = pw < p.Wp - WS ? 0 : (pw < p.Wp - p.shift ? 1 : 2);
         rid_s[tid] = (unsigned char)(fh * 3 + fw);
     }
-    for (int i = tid; i < ATT_BF16_HPW * TABN; i += (ATT_BF16_HPW * ATT_THREADS)) {
-        const int hh = i / TABN, j = i - hh * TABN;
-        rev_[hh][j] = LOG2E * p.rel_table[(blockIdx.y * ATT_BF16_HPW + hh) * TABN + (TABN - 1 - j)];
+    // ---- consume: table, K (row-major, chunk-swizzled), V (transposed); pad tokens take the qkv bias (swin.rs:359-366: their LayerNorm
+    // output row is zero) in a second, divergent step that only the windows on the padded border execute ----
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int i = tid + j * NTHR;
+        if (i < NTAB) { const int hh = i / TABN; rev_[hh][i - hh * TABN] = LOG2E * tbw[j]; }
     }
-
-    // ---- stage K (row-major, chunk-swizzled) and V (transposed): items = (token pair, head of the pair, 8-wide d chunk); 8 consecutive
-    // threads fetch the 128 contiguous bytes that hold one token's K (V) rows of both heads ----
-    for (int idx = tid; idx < (NTOK / 2) * 4 * ATT_BF16_HPW; idx += (ATT_BF16_HPW * ATT_THREADS)) {
-        const int c8 = (idx & 3) * 8, hh = (idx >> 2) & (ATT_BF16_HPW - 1), tp = idx / (4 * ATT_BF16_HPW);
-        const int hd = (blockIdx.y * ATT_BF16_HPW + hh) * HD;
-        bf16x8 kv[2], vv[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int t = tp * 2 + u, src = tok_src(t);
-            if (src >= 0) {
-                const __bf16* kp = qkv + (long)src * C3 + C + hd + c8;
-                kv[u] = *reinterpret_cast<const bf16x8*>(kp);
-                vv[u] = *reinterpret_cast<const bf16x8*>(kp + C);
-            } else {          // pad token: LayerNorm output row is zero, so q / k / v = the qkv bias (swin.rs:359-366)
-                kv[u] = bias8_bf16(p.qkv_bias + C + hd + c8);
-                vv[u] = bias8_bf16(p.qkv_bias + 2 * C + hd + c8);
+    for (int u = 0; u < 3; ++u)
+        if (qsrc_[u] < 0) qf[u] = bias8_bf16(p.qkv_bias + head * HD + g * 8);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = tid + it * NTHR;
+        if (idx < NITEM) {
+            const int c8 = (idx & 3) * 8, hh = (idx >> 2) & (ATT_BF16_HPW - 1), tp = idx / (4 * ATT_BF16_HPW);
+            const int hd = (blockIdx.y * ATT_BF16_HPW + hh) * HD;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (ssrc[it][u] < 0) {
+                    kv[it][u] = bias8_bf16(p.qkv_bias + C + hd + c8);
+                    vv[it][u] = bias8_bf16(p.qkv_bias + 2 * C + hd + c8);
+                }
             }
-        }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int t = tp * 2 + u;
-            *reinterpret_cast<bf16x8*>(Kp_[hh] + t * HD + (((c8 >> 3) ^ kswz(t)) << 3)) = kv[u];
-        }
+            for (int u = 0; u < 2; ++u) {
+                const int t = tp * 2 + u;
+                *reinterpret_cast<bf16x8*>(Kp_[hh] + t * HD + (((c8 >> 3) ^ kswz(t)) << 3)) = kv[it][u];
+            }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            bf16x2 h;
-            h[0] = vv[0][e]; h[1] = vv[1][e];
-            *reinterpret_cast<bf16x2*>(Vt_[hh] + (c8 + e) * VT_LD + tp * 2) = h;
+            for (int e = 0; e < 8; ++e) {
+                bf16x2 h;
+                h[0] = vv[it][0][e]; h[1] = vv[it][1][e];
+                *reinterpret_cast<bf16x2*>(Vt_[hh] + (c8 + e) * VT_LD + tp * 2) = h;
+            }
         }
     }
     __syncthreads();
@@ -644,9 +673,11 @@ hipError_t launch_window_attention2(const WindowAttnParams& p, const WindowAttnP
     dim3 grid(n0 + n1, p.heads), block(ATT_THREADS);
     if (p.io_bf16) {
         if (p.out_planes || (p.C & 7)) return hipErrorInvalidValue;
-        // two heads per workgroup (whole 128-byte lines per token in the staging loads) measured 1 % slower end to end (224.5 vs 226.8
-        // img/s at batch 8, tools/bench_env_ab.py BRN_ATT_HPW=1|2): kept behind the switch, one head per workgroup is the default
-        static const bool two_heads = getenv("BRN_ATT_HPW") && atoi(getenv("BRN_ATT_HPW")) == 2;
+        // (round 2, one stream: two heads per workgroup measured 1 % slower end to end, 224.5 vs 226.8 img/s at batch 8)
+        // round 3: two heads per workgroup is the default — alone the launch is 6 % slower (3.25 against 3.05 ms per 8-image step), but it reads
+        // whole 128-byte lines (one head per workgroup touches half of every line it fetches: 8.5 GB read against 5.9 algorithmic), and with
+        // two sub-batch streams sharing the HBM the step is 1.0 % faster (tools/ab_env.sh BRN_ATT_HPW "1 2"); BRN_ATT_HPW=1 selects one head
+        static const bool two_heads = !(getenv("BRN_ATT_HPW") && atoi(getenv("BRN_ATT_HPW")) == 1);
         if (two_heads && !(p.heads & 1)) hipLaunchKernelGGL(window_attention_bf16_kernel<2>, dim3(n0 + n1, p.heads / 2), dim3(2 * ATT_THREADS), 0, s, p, q, n0);
         else hipLaunchKernelGGL(window_attention_bf16_kernel<1>, grid, block, 0, s, p, q, n0);
     } else if (p.planes == 2) hipLaunchKernelGGL(window_attention_split_kernel<2>, grid, block, 0, s, p, q, n0);

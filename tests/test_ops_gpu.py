@@ -359,8 +359,8 @@ def test_window_attention_bf16_mode(gpu, B, H, W, heads, shift):
 
 
 def test_window_attention_bf16_two_heads_per_workgroup(gpu, tmp_path):
-    """the BRN_ATT_HPW=2 instantiation (two heads per workgroup; the switch is read once per process, hence the child process):
-    same cases, same reference, and bit-equal to the default instantiation"""
+    """both instantiations of window_attention_bf16_kernel — two heads per workgroup (the default for an even head count) and one
+    (BRN_ATT_HPW=1; the switch is read once per process, hence the child processes): same cases, same reference, bit-equal results"""
     import subprocess, sys, os
     code = (
         "import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
