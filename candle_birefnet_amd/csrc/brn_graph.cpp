@@ -178,6 +178,7 @@ void run_conv(Ctx& c, const GemmW& w, const Map& in, const Map& out, const float
         p.Hout = Hout; p.Wout = Wout; p.Kreal = w.Kreal;
         p.bias = w.bias; p.scale = w.scale; p.shift = w.shift; p.act = w.act;
         p.bbias_rows = 1; p.ldc = out.ld; p.c_coff = out.coff; p.c_f32 = c_f32;
+        p.k_chunk_major = w.wb_chunk_major;
         run_gemm_bf16(c, w, p, FAM_GEMM_CONV);
         return;
     }
@@ -521,10 +522,14 @@ void decoder_forward(Ctx& c, const Model& m, const float* img, int B, int H, int
     decblk_forward(c, d.dec[2], d2, p2, dm);
     gdt_gate(c, d, 2, p2);
     // stage 1 (birefnet.rs:362-369)
-    Map d1 = new_map(c, B, h1, w1, 480);
+    // (bf16-storage mode: 512 channels, the last 32 zeros written by ipt_blk2's padded conv_out: decoder_block1.conv_in runs chunk-major)
+    const int d1pad = d.dec[3].conv_in.Cinp > 480 ? d.dec[3].conv_in.Cinp - 480 : 0;
+    Map d1 = new_map(c, B, h1, w1, 480 + d1pad);
+    d1.C = 480;
     run_resize(c, p2, d1.window(0, 384));
     run_gemm(c, d.lat[2], c.at(x1.p, x1.coff), B * h1 * w1, x1.ld, d1.p, d1.ld, 0, d1.p, d1.ld, 0);
-    ipt_block(c, d.ipt[1], img, B, H, W, h1, w1, 48, d1.window(384, 96));
+    if (d.ipt[1].conv_out.N != 96 + d1pad) fail(BRN_ERR_INVALID_ARG, "ipt_blk2 / decoder_block1 channel padding mismatch");
+    ipt_block(c, d.ipt[1], img, B, H, W, h1, w1, 48, d1.window(384, 96 + d1pad));
     Map p1 = new_map(c, B, h1, w1, 192);
     decblk_forward(c, d.dec[3], d1, p1, dm);
     // head (birefnet.rs:372-375): q = <p1, w[0:192]> at 1/4 res; t = the whole ipt_blk1 branch (conv1 -> conv_out -> its

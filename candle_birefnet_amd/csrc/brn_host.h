@@ -85,6 +85,7 @@ struct GemmW {          // one Linear / Conv2d, repacked for gemm_f32
     int planes = 0, wp_rows = 0;
     void* wb = nullptr; // bf16-storage mode (BRN_BF16): plain [wb_rows][wb_ld] bf16, rows padded to 256, K padded to 64 (zeros)
     int wb_rows = 0, wb_ld = 0;
+    int wb_chunk_major = 0;   // wb's K order is (64-channel chunk, tap, channel in chunk) (channels-last convs with Cinp % 64 == 0, Cinp > 64: gemm_bf16.hip)
     void* wf = nullptr; // bf16-storage mode, deformable convs: the same matrix in MFMA fragment order [n/16][K/64][2][64 lanes][8] (kernels/deform_bf16.hip)
     int N = 0, K = 0, Kreal = 0;
     int Cin = 0, Cinp = 0, kh = 1, kw = 1, stride = 1, pad = 0, dil = 1;

@@ -45,6 +45,7 @@ struct GemmParams {
     int a_planes, c_planes;   // 2: A is read / C is written in the P2 layout (kernels/split_planes.h); split-bf16 dense ws kernel only
     // bf16-storage mode (kernels/gemm_bf16.hip): A, C, R are bf16 unless flagged; Wp is the plain [wp_rows][wp_ld] bf16 matrix
     int wp_ld;                // elements per W row (K rounded up to 64, zero padded)
+    int k_chunk_major;        // bf16 implicit GEMM: W's K order is (64-channel chunk, tap, channel in chunk) instead of (tap, channel); Cin % 64 == 0
     int c_f32, r_f32;         // 1: C is written / R is read as fp32 (offset maps of the deformable mode, fp32 side outputs)
     int a_bf16, c_bf16;       // gemm_f32_kernel only (deformable gather in bf16 mode): A map read / C written as bf16
     unsigned long long* trace;   // diagnostics only: per-workgroup cycle stamps (gemm_split_ws_kernel), null in production

@@ -94,8 +94,19 @@ static void attach_planes(DeviceOwner& own, GemmW& g, const std::vector<float>& 
         const size_t K = (size_t)g.K, ld = (K + 63) / 64 * 64;
         const size_t nrows = pk.size() / K, prow = (nrows + 255) / 256 * 256;
         std::vector<uint16_t> wb(prow * ld, 0);
+        // channels-last convs over more than one 64-channel chunk: K order (chunk, tap, channel in chunk) instead of pk's (tap, channel), so
+        // that the kh x kw taps of a chunk — which re-read the same input pixels — are consecutive K steps: the re-reads then hit L2 (tap-major
+        // order puts a whole Cin sweep of the tile's neighbourhood, > 4 MB for 32 concurrent tiles of the decoder's conv_in, between them)
+        static const bool cm_off = getenv("BRN_CONV_CHUNK_MAJOR") && atoi(getenv("BRN_CONV_CHUNK_MAJOR")) == 0;
+        const bool cm = !cm_off && g.mode == GEMM_CONV_NHWC && g.Cinp % 64 == 0 && g.Cinp > 64 && (size_t)g.kh * g.kw * g.Cinp == K;
+        const size_t kk = (size_t)g.kh * g.kw, cinp = (size_t)g.Cinp;
         for (size_t r = 0; r < nrows; ++r)
-            for (size_t k = 0; k < K; ++k) wb[r * ld + k] = bf16_rne(pk[r * K + k]);
+            for (size_t k = 0; k < K; ++k) {
+                size_t kd = k;
+                if (cm) { const size_t t = k / cinp, ci = k - t * cinp; kd = ((ci >> 6) * kk + t) * 64 + (ci & 63); }
+                wb[r * ld + kd] = bf16_rne(pk[r * K + k]);
+            }
+        g.wb_chunk_major = cm ? 1 : 0;
         void* d = nullptr;
         hipError_t e = hipMalloc(&d, wb.size() * 2 + 16);
         if (e != hipSuccess) fail(BRN_ERR_OOM, "hipMalloc of %zu bytes failed: %s", wb.size() * 2, hipGetErrorString(e));
@@ -321,7 +332,10 @@ void build_decblk_weights(const WeightTable& wt, const std::string& p, int cin, 
     const int IC = 64;             // inter_channels (decoder.rs:96)
     out.cin = cin; out.cout = cout;
     if (cin % 32) fail(BRN_ERR_INVALID_ARG, "decoder block in_channels %d must be a multiple of 32", cin);
-    out.conv_in = conv_bn(wt, p + "conv_in", true, p + "bn_in", IC, cin, cin, 3, 1, ACT_RELU, own);
+    // (bf16-storage mode: an input channel count that is not a multiple of 64 — decoder_block1's 480 — is padded with zero weights to the
+    // next multiple, so that the conv runs chunk-major; the caller's map then carries that many channels, the pad ones zero)
+    const int cin_pad = (g_build_planes == BUILD_BF16 && cin % 64) ? roundup(cin, 64) : cin;
+    out.conv_in = conv_bn(wt, p + "conv_in", true, p + "bn_in", IC, cin, cin_pad, 3, 1, ACT_RELU, own);
     out.conv_out = conv_bn(wt, p + "conv_out", true, p + "bn_out", cout, IC, IC, 3, 1, ACT_NONE, own);   // no ReLU (decoder.rs:138-139)
     build_aspp_weights(wt, p + "dec_att.", deform_mode, own, out.aspp);
 }
@@ -420,6 +434,16 @@ void build_decoder_weights(const WeightTable& wt, const std::string& p, const br
         out.ipt[i].conv1 = make_conv_nhwc(own, w, b, 64, cin, cinp, 3, 3, 1, 1, 1);
         const float* w2 = wt.get(ip + "conv_out.weight", {ipt_out[i], 64, 3, 3})->data;
         const float* b2 = wt.get(ip + "conv_out.bias", {ipt_out[i]})->data;
+        // bf16-storage mode: the consumer of ipt_blk2 (decoder_block1.conv_in, 384 + 96 = 480 input channels) reads a map padded to 512
+        // channels so that its K loop can run chunk-major (attach_planes); the 32 pad channels must hold zeros, and the cheapest writer
+        // is this conv with 32 extra all-zero output channels (weights and bias zero: exact zeros, no activation follows)
+        const int opad = (g_build_planes == BUILD_BF16 && ipt_out[i] == 96) ? 128 : ipt_out[i];
+        if (opad != ipt_out[i]) {
+            std::vector<float> wz((size_t)opad * 64 * 9, 0.f), bz(opad, 0.f);
+            memcpy(wz.data(), w2, (size_t)ipt_out[i] * 64 * 9 * sizeof(float));
+            memcpy(bz.data(), b2, (size_t)ipt_out[i] * sizeof(float));
+            out.ipt[i].conv_out = make_conv_nhwc(own, wz.data(), bz.data(), opad, 64, 64, 3, 3, 1, 1, 1);
+        } else
         out.ipt[i].conv_out = make_conv_nhwc(own, w2, b2, ipt_out[i], 64, 64, 3, 3, 1, 1, 1);
     }
     const int dec_out[4] = {lat[2], lat[1], lat[0], lat[0] / 2};          // [1536,768,384,192] birefnet.rs:202

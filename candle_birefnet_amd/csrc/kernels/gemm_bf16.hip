@@ -305,8 +305,15 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
         }
         if (MODE == GEMM_CONV_NHWC) {
             const int k = kt0 * BBK + kch;
-            const int tap = k / p.Cin;
-            c_ci = k - tap * p.Cin;
+            int tap;
+            if (p.k_chunk_major) {         // K order (64-channel chunk, tap, channel in chunk): the taps of a chunk re-read the same pixels back to back
+                const int per = p.kh * p.kw * 64, ch = k / per, rem = k - ch * per;
+                tap = rem >> 6;
+                c_ci = ch * 64 + (rem & 63);
+            } else {
+                tap = k / p.Cin;
+                c_ci = k - tap * p.Cin;
+            }
             c_ky = tap / p.kw; c_kx = tap - c_ky * p.kw;
             tap_off = ((c_ky * p.dil) * p.Win + c_kx * p.dil) * p.lda * 2 + c_ci * 2;
             const int b0 = min(m0, p.M - 1) / (p.Hout * p.Wout);
@@ -337,7 +344,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
                 // implicit GEMM: buffer-addressed too — the lane's pixel offset is fixed for the tile, its (tap, channel) offset is kept
                 // incrementally, and a tap outside the image (or beyond the last tap: K tail) gets an offset past num_records, which
                 // the buffer unit answers with zeros (no zero page, no 64-bit address arithmetic)
-                const bool kin = c_ky < p.kh;
+                const bool kin = p.k_chunk_major ? c_ci < p.Cin : c_ky < p.kh;
                 const int iy = a_iy[j] + c_ky * p.dil, ix = a_ix[j] + c_kx * p.dil;
                 const bool ok = a_ok[j] && kin && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
                 const unsigned voff = ok ? (unsigned)(a_pix[j] + tap_off) : 0x80000000u;
@@ -350,7 +357,10 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
         }
     };
     auto stage_advance = [&]() {
-        if (MODE == GEMM_CONV_NHWC) {
+        if (MODE == GEMM_CONV_NHWC && p.k_chunk_major) {        // next tap of the same 64-channel chunk; after the last tap the next chunk
+            if (++c_kx == p.kw) { c_kx = 0; if (++c_ky == p.kh) { c_ky = 0; c_ci += 64; } }
+            tap_off = ((c_ky * p.dil) * p.Win + c_kx * p.dil) * p.lda * 2 + c_ci * 2;
+        } else if (MODE == GEMM_CONV_NHWC) {
             c_ci += BBK;
             tap_off += BBK * 2;
             if (c_ci >= p.Cin) {
@@ -899,6 +909,7 @@ hipError_t launch_gemm_bf16(const GemmParams& p_in, const GemmPlan& pl, float* w
     if ((p_in.lda | p_in.a_coff) & 7) return hipErrorInvalidValue;                       // 16-byte chunks of 8 bf16
     if (p_in.wp_ld < (p_in.K + 63) / 64 * 64 || (p_in.wp_ld & 7)) return hipErrorInvalidValue;
     if (p_in.mode == GEMM_CONV_NHWC && ((p_in.Cin & 31) || p_in.Cin < 64 || p_in.K != p_in.kh * p_in.kw * p_in.Cin)) return hipErrorInvalidValue;
+    if (p_in.k_chunk_major && (p_in.mode != GEMM_CONV_NHWC || (p_in.Cin & 63))) return hipErrorInvalidValue;
     if (p_in.mode != GEMM_DENSE && p_in.mode != GEMM_CONV_NHWC) return hipErrorInvalidValue;
     if (p_in.mode == GEMM_CONV_NHWC && (double)p_in.Hin * p_in.Win * p_in.lda * 2.0 >= 1073741824.0) return hipErrorInvalidValue;   // 32-bit buffer offsets span two images
     const int bn_need = pl.cfg == 1 ? 64 : ((pl.cfg == 2 || pl.cfg == 19) ? 256 : (pl.cfg == 3 ? 192 : 128));

@@ -269,10 +269,13 @@ def test_linear_bf16_mode(gpu, M, K, N, act):
 
 
 @pytest.mark.parametrize("B,C,H,W,O,k,p", [(2, 64, 16, 16, 256, 3, 1), (1, 64, 20, 12, 256, 7, 3), (1, 96, 9, 11, 64, 3, 1), (1, 480, 12, 12, 64, 3, 1),
-                                           (1, 64, 33, 17, 192, 3, 1), (2, 3456, 8, 8, 64, 3, 1), (1, 64, 24, 24, 16, 3, 1)])
+                                           (1, 64, 33, 17, 192, 3, 1), (2, 3456, 8, 8, 64, 3, 1), (1, 64, 24, 24, 16, 3, 1),
+                                           (1, 128, 20, 20, 64, 3, 1), (2, 192, 15, 17, 192, 3, 1), (1, 960, 12, 12, 64, 3, 1), (1, 128, 13, 13, 256, 7, 3),
+                                           (1, 1920, 16, 16, 64, 3, 1)])
 def test_conv2d_bf16_mode(gpu, B, C, H, W, O, k, p):
     """implicit-GEMM conv on bf16 maps: zero padding through out-of-range buffer offsets (answered with zeros), Cin = 480 (K steps that straddle taps, K % 64 = 32),
-    ragged maps, the tall-K split-K plan (3456 x 9), N = 16 (scalar stores).  The output map is bf16: tolerance = one bf16 ulp."""
+    ragged maps, the tall-K split-K plan (3456 x 9), N = 16 (scalar stores); Cin = 128 / 192 / 960 / 1920 / 3456 run the chunk-major K
+    order (64-channel chunk, tap, channel), 3x3 and 7x7, with and without split-K.  The output map is bf16: tolerance = one bf16 ulp."""
     from candle_birefnet_amd import ops
     x, w, b = rnd(B, C, H, W, seed=1), rnd(O, C, k, k, seed=2, std=(C * k * k) ** -0.5), rnd(O, seed=3, std=0.1)
     ops.set_compute("bf16")
