@@ -40,9 +40,13 @@ constexpr int ATT_THREADS = 192;   // 3 waves, 3 query tiles each
 // WSZ = window side: 12 (Swin-B / L, swin.rs:60,74) or 7 (Swin-T / S, swin.rs:32,46); head_dim is 32 in all four configurations.
 // A window holds WSZ^2 tokens = NT16 key / query tiles of 16; the tail of the last tile (49 -> 64) is dummy: zero K / V rows, scores
 // forced to -3e38 so that they leave the softmax, queries never stored.
-template <int WSZ>
-__global__ void __launch_bounds__(ATT_THREADS) window_attention_f32_kernel(const WindowAttnParams pa, const WindowAttnParams pb, const int nblk0) {
+// NWV = waves per workgroup: 3 (three query tiles each at window 12) or 9 (one query tile each: the workgroup lives a third as long on
+// the same 41.5 KB of LDS = 3 workgroups per CU; at batch 1 a stage-2 launch is 1080 workgroups on 768 slots = two rounds whatever
+// the wave count, so the round time is what counts)
+template <int WSZ, int NWV = 3>
+__global__ void __launch_bounds__(NWV * 64) window_attention_f32_kernel(const WindowAttnParams pa, const WindowAttnParams pb, const int nblk0) {
     constexpr int WS = WSZ, NTOK = WSZ * WSZ, NT16 = (NTOK + 15) / 16, NPADTOK = NT16 * 16;
+    constexpr int NTHR = NWV * 64;
     const bool second = (int)blockIdx.x >= nblk0;
     const WindowAttnParams& p = second ? pb : pa;
     __shared__ __attribute__((aligned(16))) float Ks[NPADTOK * KV_LD];
@@ -76,13 +80,13 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_f32_kernel(const
     constexpr int TABN = (2 * WS - 1) * (2 * WS - 1);
     constexpr bool REV = WS == 12;
     constexpr float LOG2E = 1.4426950408889634f;
-    for (int i = tid; i < TABN; i += ATT_THREADS) tab_s[i] = REV ? LOG2E * p.rel_table[head * TABN + (TABN - 1 - i)] : p.rel_table[head * TABN + i];
+    for (int i = tid; i < TABN; i += NTHR) tab_s[i] = REV ? LOG2E * p.rel_table[head * TABN + (TABN - 1 - i)] : p.rel_table[head * TABN + i];
     // the shift mask (swin.rs:283-296) is non-zero only in the last row / column of windows
     const bool has_mask = p.shift > 0 && (wr == p.Hp / WS - 1 || wc == nWw - 1);
     __syncthreads();
 
     // ---- stage K and V of this (window, head) into LDS: 144 rows x 8 float4 each ----
-    for (int idx = tid; idx < NPADTOK * 8; idx += ATT_THREADS) {
+    for (int idx = tid; idx < NPADTOK * 8; idx += NTHR) {
         const int t = idx >> 3, c4 = (idx & 7) * 4;
         const int src = src_s[t];
         const float* kp = src >= 0 ? p.qkv + (long)src * C3 + C + head * HD + c4 : p.qkv_bias + C + head * HD + c4;
@@ -106,7 +110,7 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_f32_kernel(const
     };
     f32x4 qn0 = {0.f, 0.f, 0.f, 0.f}, qn1 = qn0;
     if (wave < NT16) load_q(wave, qn0, qn1);
-    for (int qt = wave; qt < NT16; qt += 3) {
+    for (int qt = wave; qt < NT16; qt += NWV) {
         const int qtok = qt * 16 + li;
         const int qsrc = src_s[qtok];
         const int qrid = rid_s[qtok];
@@ -117,7 +121,7 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_f32_kernel(const
         float qf[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { qf[e] = qn0[e] * p.scale; qf[4 + e] = qn1[e] * p.scale; }
-        if (qt + 3 < NT16) load_q(qt + 3, qn0, qn1);
+        if (qt + NWV < NT16) load_q(qt + NWV, qn0, qn1);
         // S^T = K . Q^T : 9 key tiles
         f32x4 st[NT16];
 #pragma unroll
@@ -687,7 +691,11 @@ hipError_t launch_window_attention2(const WindowAttnParams& p, const WindowAttnP
     else if (p.planes == 1) return hipErrorInvalidValue;      // mode bf16_operands: diag build only
 #endif
     else if (ws == 7) hipLaunchKernelGGL(window_attention_f32_kernel<7>, grid, block, 0, s, p, q, n0);
-    else hipLaunchKernelGGL(window_attention_f32_kernel<12>, grid, block, 0, s, p, q, n0);
+    else {
+        static const int f32_waves = getenv("BRN_ATT_F32_WAVES") ? atoi(getenv("BRN_ATT_F32_WAVES")) : 9;
+        if (f32_waves == 9) hipLaunchKernelGGL((window_attention_f32_kernel<12, 9>), grid, dim3(9 * 64), 0, s, p, q, n0);
+        else hipLaunchKernelGGL((window_attention_f32_kernel<12, 3>), grid, block, 0, s, p, q, n0);
+    }
     return hipGetLastError();
 }
 hipError_t launch_window_attention(const WindowAttnParams& p, hipStream_t s) { return launch_window_attention2(p, nullptr, s); }
