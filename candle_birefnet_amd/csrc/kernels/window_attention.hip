@@ -437,6 +437,12 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_split_kernel(con
 // (16-byte loads of 8 bf16, no split) and that q's scale is applied to the fp32 scores instead of to q (q is already
 // rounded to bf16: scaling the accumulator avoids a second rounding; identical in real arithmetic, swin.rs:278).
 // =====================================================================================================================
+// v_max3_f32 without the canonicalising v_max x, x that fmaxf puts in front of it (the scores are MFMA / fma results: never signalling)
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ bf16x8 bias8_bf16(const float* bp) {
     bf16x8 r;
 #pragma unroll
@@ -567,6 +573,9 @@ __global__ void __launch_bounds__(ATT_BF16_HPW * ATT_THREADS) __attribute__((amd
     __syncthreads();
 
     const float scale2 = p.scale * LOG2E;
+    bf16x8 ones8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones8[e] = (__bf16)1.0f;
     // per key tile: koff = key0 + 11 (key0 / 12) for key0 = 16 kt + 4 g; the table word of (query, key0 + r) is rev[qrev + koff + r]
     int koff[9];
 #pragma unroll
@@ -576,7 +585,7 @@ __global__ void __launch_bounds__(ATT_BF16_HPW * ATT_THREADS) __attribute__((amd
         const int qt = wv + 3 * u;
         const int qtok = qt * 16 + li;
         const int qsrc = qsrc_[u];
-        const int qrid = rid_s[qtok];
+        const unsigned qrid4 = 0x01010101u * (unsigned)rid_s[qtok];
         // table index of (query, key) = qbase - key - 11 (key / 12), qbase = (qi + 11) 23 + qj + 11 (swin.rs:143-152 arithmetically)
         const int qrev = (TABN - 1) - ((qtok / WS + WS - 1) * (2 * WS - 1) + (qtok % WS) + WS - 1);
         f32x4 st[9];
@@ -598,28 +607,25 @@ __global__ void __launch_bounds__(ATT_BF16_HPW * ATT_THREADS) __attribute__((amd
         if (has_mask) {
 #pragma unroll
             for (int kt = 0; kt < 9; ++kt) {
-                const unsigned rw = *reinterpret_cast<const unsigned*>(rid_s + kt * 16 + g * 4);
+                // byte r of x is non-zero where key r lies in another region than the query: one byte-to-float conversion and one fma per
+                // score.  A region distance d > 1 adds -100 d instead of -100: both are weights below 1e-43 (swin.rs:283-296 adds -100)
+                const unsigned x = *reinterpret_cast<const unsigned*>(rid_s + kt * 16 + g * 4) ^ qrid4;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) st[kt][r] += ((int)((rw >> (8 * r)) & 0xffu) != qrid) ? -100.0f * LOG2E : 0.0f;
+                for (int r = 0; r < 4; ++r) st[kt][r] = fmaf((float)((x >> (8 * r)) & 0xffu), -100.0f * LOG2E, st[kt][r]);
             }
         }
 #pragma unroll
-        for (int kt = 0; kt < 9; ++kt) mx = fmaxf(fmaxf(mx, fmaxf(st[kt][0], st[kt][1])), fmaxf(st[kt][2], st[kt][3]));
+        for (int kt = 0; kt < 9; ++kt) mx = max3f(max3f(mx, st[kt][0], st[kt][1]), st[kt][2], st[kt][3]);
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 9; ++kt) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = __builtin_amdgcn_exp2f(st[kt][r] - mx);
-                st[kt][r] = e;
-                sum += e;
-            }
+            for (int r = 0; r < 4; ++r) st[kt][r] = __builtin_amdgcn_exp2f(st[kt][r] - mx);
         }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
-        f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+        // the row sums come out of the matrix pipe: a third "V" tile of ones makes every row of osum the sum over the keys of the
+        // SAME bf16 weights the P V product uses (36 adds and two cross-lane steps per query tile less on the vector pipe)
+        f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f}, osum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 5; ++t) {
             bf16x8 pf;
@@ -640,10 +646,11 @@ __global__ void __launch_bounds__(ATT_BF16_HPW * ATT_THREADS) __attribute__((amd
                 if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o0, 0, 0, 0);
                 else o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o1, 0, 0, 0);
             }
+            osum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones8, pf, osum, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (qsrc >= 0) {
-            const float inv = 1.0f / sum;
+            const float inv = __builtin_amdgcn_rcpf(osum[0]);
             __bf16* op = reinterpret_cast<__bf16*>(p.out) + (long)qsrc * C + head * HD + g * 4;
             bf16x4 h0, h1;
 #pragma unroll
