@@ -180,10 +180,30 @@ static void run_model(Model* m, const float* x, int B, int H, int W, brn_mem in_
     // loops of the others (measured at batch 8, 1024^2, bf16: +5.6 % with 2 parts).  BRN_SPLIT_STREAMS = number of
     // parts (default 2; 1 = one stream).  Each part has its own workspace; the results do not depend on how the host interleaves the
     // enqueues (same kernels, same plans per part, no atomics).  Profiled forwards run on one stream (per-launch events).
+    // Independent branches of one forward (ASPP branches, the image-patch convolutions) go to auxiliary streams (brn_graph.cpp: Branch);
+    // BRN_BRANCH_STREAMS=0 keeps everything on the forward's own stream.
+    // Default: on when the batch runs as ONE part (measured: +1.4 % at batch 1, 1024^2; with two sub-batch streams the extra
+    // concurrency costs 2.5 % at batch 8); a positive value is the mask of auxiliary streams to use, for every batch
+    // (31 = all: 7 the ASPP branches, 8 the image-patch convolutions, 16 the lateral convolutions).
+    static const int branches_env = getenv("BRN_BRANCH_STREAMS") ? atoi(getenv("BRN_BRANCH_STREAMS")) : -1;
+    bool branches_on = branches_env != 0;
+    auto branch_set = [&](int k) -> BranchSet* {
+        if (!branches_on || m->profiling) return nullptr;
+        if ((int)m->branch_sets.size() <= k) m->branch_sets.resize(k + 1);
+        BranchSet& bs = m->branch_sets[k];
+        for (int i = 0; i < BRN_AUX_STREAMS; ++i) {
+            if (bs.stream[i]) continue;
+            BRN_HIP(hipStreamCreateWithFlags(&bs.stream[i], hipStreamNonBlocking));
+            BRN_HIP(hipEventCreateWithFlags(&bs.fork_ev[i], hipEventDisableTiming));
+            BRN_HIP(hipEventCreateWithFlags(&bs.join_ev[i], hipEventDisableTiming));
+        }
+        return &bs;
+    };
     static const int parts_env = getenv("BRN_SPLIT_STREAMS") ? atoi(getenv("BRN_SPLIT_STREAMS")) : 2;
     int parts = parts_env < 1 ? 1 : (parts_env > 8 ? 8 : parts_env);
     if (parts > B / 2) parts = B / 2;                              // at least two images per part
     if (parts > 1 && !m->profiling && in_loc == BRN_MEM_DEVICE && out_loc == BRN_MEM_DEVICE) {
+        if (branches_env < 0) branches_on = false;
         if (!m->fork_ev) BRN_HIP(hipEventCreateWithFlags(&m->fork_ev, hipEventDisableTiming));
         if ((int)m->sides.size() < parts - 1) m->sides.resize(parts - 1);
         for (int k = 0; k < parts - 1; ++k) {
@@ -209,6 +229,8 @@ static void run_model(Model* m, const float* x, int B, int H, int W, brn_mem in_
             if (k > 0) BRN_HIP(hipStreamWaitEvent(sk, m->fork_ev, 0));
             Ctx ck{k == 0 ? &m->arena : &m->sides[k - 1].arena, sk, false, false, nullptr, nullptr, nullptr};
             ck.bf16 = m->bf16;
+            ck.br = branch_set(k);
+            if (branches_env > 0) ck.br_mask = (unsigned)branches_env;
             model_forward(*m, ck, dx + (size_t)b0 * 3 * H * W, bk, H, W, dout + (size_t)b0 * H * W, apply_sigmoid);
             if (k > 0) BRN_HIP(hipEventRecord(m->sides[k - 1].join_ev, sk));
             b0 += bk;
@@ -220,6 +242,8 @@ static void run_model(Model* m, const float* x, int B, int H, int W, brn_mem in_
     }
     Ctx c{&m->arena, s, false, m->profiling, &m->records, &m->event_pool, &m->event_next};
     c.bf16 = m->bf16;
+    c.br = branch_set(0);
+    if (branches_env > 0) c.br_mask = (unsigned)branches_env;
     model_forward(*m, c, dx, B, H, W, dout, apply_sigmoid);
     if (out_loc == BRN_MEM_HOST) {
         BRN_HIP(hipMemcpyAsync(out, dout, n_out * sizeof(float), hipMemcpyDeviceToHost, s));

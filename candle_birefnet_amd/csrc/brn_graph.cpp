@@ -52,6 +52,38 @@ struct Bracket {
         if (e_ != hipSuccess) fail(BRN_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));        \
     } while (0)
 
+// ---- graph branches on auxiliary streams --------------------------------------------------------------------------------
+// While a Branch is alive, launches go to aux stream k, ordered after everything enqueued on the main stream so far; join_branches
+// makes the main stream wait for every branch enqueued since the last join.  Same kernels, same arguments, same results: only
+// the order in which independent launches may run changes.  Buffers a branch writes must stay allocated until the join (Arena::hold).
+struct Branch {
+    Ctx& c; hipStream_t main; int k; bool on;
+    Branch(Ctx& c_, int k_) : c(c_), main(c_.stream), k(k_), on(c_.br && !c_.dry && !c_.profile && k_ >= 0 && k_ < BRN_AUX_STREAMS && ((c_.br_mask >> k_) & 1u)) {
+        if (!on) return;
+        BRN_HIP(hipEventRecord(c.br->fork_ev[k], main));
+        BRN_HIP(hipStreamWaitEvent(c.br->stream[k], c.br->fork_ev[k], 0));
+        c.stream = c.br->stream[k];
+    }
+    ~Branch() {
+        if (!on) return;
+        (void)hipEventRecord(c.br->join_ev[k], c.stream);
+        c.stream = main;
+        c.pending |= 1u << k;
+    }
+};
+static void join_branches(Ctx& c, unsigned mask) {
+    for (int k = 0; k < BRN_AUX_STREAMS; ++k)
+        if (c.pending & mask & (1u << k)) BRN_HIP(hipStreamWaitEvent(c.stream, c.br->join_ev[k], 0));
+    c.pending &= ~mask;
+}
+constexpr int AUX_IPT = 3, AUX_LAT = 4;
+constexpr unsigned AUX_ASPP_MASK = 7u;
+struct ArenaHold {
+    Arena& a;
+    explicit ArenaHold(Arena& a_) : a(a_) { ++a.hold; }
+    ~ArenaHold() { --a.hold; }
+};
+
 // ---- GEMM-shaped pieces -------------------------------------------------------------------------------------------------
 static void fill_epilogue(GemmParams& p, const GemmW& w) {
     p.bias = w.bias; p.scale = w.scale; p.shift = w.shift; p.act = w.act;
@@ -253,11 +285,11 @@ void run_layernorm(Ctx& c, const LNW& ln, const float* x, int rows, int ldx, flo
     BRN_LAUNCH(launch_layernorm(p, c.stream));
 }
 
-void run_resize(Ctx& c, const Map& in, const Map& out) {
+void run_resize(Ctx& c, const Map& in, const Map& out, bool accumulate) {
     if (in.C != out.C || in.B != out.B) fail(BRN_ERR_INVALID_ARG, "resize: channel/batch mismatch");
     if (c.dry) return;
-    Bracket b(c, FAM_RESIZE, 0.0, (double)c.esz() * ((double)in.pixels() + (double)out.pixels()) * in.C);
-    BRN_LAUNCH(launch_resize_nhwc(in.p, in.B, in.H, in.W, in.C, in.ld, in.coff, out.p, out.H, out.W, out.ld, out.coff, c.stream, c.bf16));
+    Bracket b(c, FAM_RESIZE, 0.0, (double)c.esz() * ((double)in.pixels() + (double)out.pixels() * (accumulate ? 2 : 1)) * in.C);
+    BRN_LAUNCH(launch_resize_nhwc(in.p, in.B, in.H, in.W, in.C, in.ld, in.coff, out.p, out.H, out.W, out.ld, out.coff, c.stream, c.bf16, accumulate ? 1 : 0));
 }
 
 // ---- Swin --------------------------------------------------------------------------------------------------------------
@@ -430,37 +462,44 @@ void aspp_forward(Ctx& c, const ASPPW& a, const Map& t, const Map& u, int deform
     const int region0 = c.region;
     c.region = REGION_ASPP;
     Map cat = new_map(c, B, H, W, 1024);                             // [aspp1 | deform k1 | k3 | k7]; pooled branch -> bias
-    if (deform_mode == BRN_DEFORM_REFERENCE_CPU) {
-        run_gemm(c, a.k1pair, t.p, M, 64, cat.p, 1024, 0);           // aspp1 + aspp_deforms.0 (regular 1x1, BN, ReLU)
-        run_conv(c, a.d[2].regular, t, cat.window(512, 256));        // k3
-        run_conv(c, a.d[3].regular, t, cat.window(768, 256));        // k7
-    } else {
-        for (int i = 0; i < 4; ++i) {
-            const DeformW& d = a.d[i];
-            const int kk = d.k * d.k, ldom = roundup(3 * kk, 4);
-            const size_t mk2 = c.arena->mark();
-            Map om; om.B = B; om.H = H; om.W = W; om.C = 3 * kk; om.ld = ldom; om.coff = 0;
-            om.p = c.arena->alloc((size_t)M * ldom);                 // offsets / modulator stay fp32 in every mode
-            run_conv(c, d.offmod, t, om, nullptr, 0, 0, 1);          // offset_conv | modulator_conv (aspp.rs:171,173)
-            const bool fused_sig = deform_fused_sigmoid(c, d.regular);   // bf16 gather kernel: 2*sigmoid applied where the modulator is read
-            if (!c.dry && !fused_sig) {
-                Bracket b(c, FAM_ELEMENTWISE, 0.0, 8.0 * M * kk);
-                BRN_LAUNCH(launch_mod_sigmoid2(om.p, (size_t)M, ldom, 2 * kk, 3 * kk, c.stream));   // 2*sigmoid (aspp.rs:174)
-            }
-            run_conv(c, d.regular, t, cat.window(256 * i, 256), om.p, ldom, 2 * kk, 0, fused_sig ? 1 : 0);
-            c.arena->release(mk2);
-        }
-    }
-    // pooled branch: mean over H then W (aspp.rs:314), 1x1 conv (no bias) + BN + ReLU, nearest-broadcast (aspp.rs:315-318)
     float* g0 = c.arena->alloc((size_t)B * 64);
     float* g1 = c.arena->alloc((size_t)B * 256);
     float* gb = c.arena->alloc((size_t)B * 64);
     float* gscr = c.arena->alloc(gap_scratch_floats(B, H * W, 64));
-    if (!c.dry) {
-        Bracket b(c, FAM_ELEMENTWISE, 0.0, 4.0 * M * 64);
-        BRN_LAUNCH(launch_gap_nhwc(t.p, B, H * W, 64, 64, 0, gscr, g0, c.stream, c.bf16));
-        BRN_LAUNCH(launch_small_fc(g0, B, 64, a.gap_w, 64, 0, 256, a.gap_scale, a.gap_shift, ACT_RELU, g1, c.stream));
-        BRN_LAUNCH(launch_small_fc(g1, B, 256, a.conv1_full, 1280, 1024, 64, nullptr, nullptr, ACT_NONE, gb, c.stream));
+    {
+        // the branches only share their input t: each runs on its own stream (the 7 x 7 branch, the longest, stays on the main one)
+        ArenaHold hold(*c.arena);
+        {
+            // pooled branch: mean over H then W (aspp.rs:314), 1x1 conv (no bias) + BN + ReLU, nearest-broadcast (aspp.rs:315-318)
+            Branch br(c, 2);
+            if (!c.dry) {
+                Bracket b(c, FAM_ELEMENTWISE, 0.0, 4.0 * M * 64);
+                BRN_LAUNCH(launch_gap_nhwc(t.p, B, H * W, 64, 64, 0, gscr, g0, c.stream, c.bf16));
+                BRN_LAUNCH(launch_small_fc(g0, B, 64, a.gap_w, 64, 0, 256, a.gap_scale, a.gap_shift, ACT_RELU, g1, c.stream));
+                BRN_LAUNCH(launch_small_fc(g1, B, 256, a.conv1_full, 1280, 1024, 64, nullptr, nullptr, ACT_NONE, gb, c.stream));
+            }
+        }
+        if (deform_mode == BRN_DEFORM_REFERENCE_CPU) {
+            { Branch br(c, 0); run_gemm(c, a.k1pair, t.p, M, 64, cat.p, 1024, 0); }           // aspp1 + aspp_deforms.0 (regular 1x1, BN, ReLU)
+            { Branch br(c, 1); run_conv(c, a.d[2].regular, t, cat.window(512, 256)); }       // k3
+            run_conv(c, a.d[3].regular, t, cat.window(768, 256));                             // k7
+        } else {
+            for (int i = 0; i < 4; ++i) {
+                Branch br(c, i < 3 ? i : -1);
+                const DeformW& d = a.d[i];
+                const int kk = d.k * d.k, ldom = roundup(3 * kk, 4);
+                Map om; om.B = B; om.H = H; om.W = W; om.C = 3 * kk; om.ld = ldom; om.coff = 0;
+                om.p = c.arena->alloc((size_t)M * ldom);             // offsets / modulator stay fp32 in every mode
+                run_conv(c, d.offmod, t, om, nullptr, 0, 0, 1);      // offset_conv | modulator_conv (aspp.rs:171,173)
+                const bool fused_sig = deform_fused_sigmoid(c, d.regular);   // bf16 gather kernel: 2*sigmoid applied where the modulator is read
+                if (!c.dry && !fused_sig) {
+                    Bracket b(c, FAM_ELEMENTWISE, 0.0, 8.0 * M * kk);
+                    BRN_LAUNCH(launch_mod_sigmoid2(om.p, (size_t)M, ldom, 2 * kk, 3 * kk, c.stream));   // 2*sigmoid (aspp.rs:174)
+                }
+                run_conv(c, d.regular, t, cat.window(256 * i, 256), om.p, ldom, 2 * kk, 0, fused_sig ? 1 : 0);
+            }
+        }
+        join_branches(c, AUX_ASPP_MASK);
     }
     run_gemm(c, a.conv1_main, cat.p, M, 1024, u.p, 64, 0, nullptr, 0, 0, gb, H * W);   // conv1 + bn1 + relu (aspp.rs:329-331)
     c.region = region0;
@@ -494,42 +533,70 @@ static void gdt_gate(Ctx& c, const DecoderW& d, int i, const Map& p) {
     c.arena->release(mk);
 }
 
+static DecMaps alloc_dec_maps(Ctx& c, const Model& m, int B, int H, int W) {
+    const DecoderW& d = m.dec;
+    DecMaps dm;
+    dm.d3 = new_map(c, B, H / 16, W / 16, 1920);
+    dm.d2 = new_map(c, B, H / 8, W / 8, 960);
+    // (bf16-storage mode: 512 channels, the last 32 zeros written by ipt_blk2's padded conv_out: decoder_block1.conv_in runs chunk-major)
+    const int d1pad = d.dec[3].conv_in.Cinp > 480 ? d.dec[3].conv_in.Cinp - 480 : 0;
+    if (d.ipt[1].conv_out.N != 96 + d1pad) fail(BRN_ERR_INVALID_ARG, "ipt_blk2 / decoder_block1 channel padding mismatch");
+    dm.d1 = new_map(c, B, H / 4, W / 4, 480 + d1pad);
+    dm.d1.C = 480;
+    return dm;
+}
+// ipt_blk5 .. ipt_blk2 (birefnet.rs:304-305,335-337,350-352,365-366): they read only the image and write the last channels of
+// the concat maps, so they can run any time before the decoder block that reads the map
+static void ipt_blocks(Ctx& c, const Model& m, const float* img, int B, int H, int W, const Map& d4, const DecMaps& dm) {
+    const DecoderW& d = m.dec;
+    ipt_block(c, d.ipt[4], img, B, H, W, H / 32, W / 32, 3072, d4.window(3072, 384));
+    ipt_block(c, d.ipt[3], img, B, H, W, H / 16, W / 16, 768, dm.d3.window(1536, 384));   // ipt4_up is a same-size resize = identity
+    ipt_block(c, d.ipt[2], img, B, H, W, H / 8, W / 8, 192, dm.d2.window(768, 192));
+    ipt_block(c, d.ipt[1], img, B, H, W, H / 4, W / 4, 48, dm.d1.window(384, dm.d1.ld - 384));
+}
+
+// lateral_block4 / 3 / 2 (1x1 convs of the backbone maps, birefnet.rs:333,348,363) written into [0:C) of the concat maps BEFORE the
+// up-sampled decoder map is added there (run_resize accumulates): they depend on the backbone only, so they can overlap the
+// squeeze module and decoder_block4, whose launches fill a fraction of the chip.  fp32 maps only: (conv + bias) + resized and
+// resized + (conv + bias) are the same fp32 sum, while on bf16 maps the stored conv result would be rounded once more.
+static void lateral_blocks(Ctx& c, const Model& m, int B, int H, int W, const Map& x1, const Map& x2, const Map& x3, const DecMaps& dm) {
+    const DecoderW& d = m.dec;
+    run_gemm(c, d.lat[0], c.at(x3.p, x3.coff), B * (H / 16) * (W / 16), x3.ld, dm.d3.p, dm.d3.ld, 0);
+    run_gemm(c, d.lat[1], c.at(x2.p, x2.coff), B * (H / 8) * (W / 8), x2.ld, dm.d2.p, dm.d2.ld, 0);
+    run_gemm(c, d.lat[2], c.at(x1.p, x1.coff), B * (H / 4) * (W / 4), x1.ld, dm.d1.p, dm.d1.ld, 0);
+}
+
 void decoder_forward(Ctx& c, const Model& m, const float* img, int B, int H, int W, const Map& x1, const Map& x2, const Map& x3,
-                     const Map& d4, float* out, int apply_sigmoid) {
+                     const Map& d4, float* out, int apply_sigmoid, const DecMaps* pre) {
     const DecoderW& d = m.dec;
     const int dm = m.cfg.deform_mode;
     const int h4 = H / 32, w4 = W / 32, h3 = H / 16, w3 = W / 16, h2 = H / 8, w2 = W / 8, h1 = H / 4, w1 = W / 4;
     const size_t mk = c.arena->mark();
+    const DecMaps maps = pre ? *pre : alloc_dec_maps(c, m, B, H, W);
+    if (!pre) ipt_blocks(c, m, img, B, H, W, d4, maps);
+    else join_branches(c, 1u << AUX_IPT);
+    const bool lat_done = pre && pre->lat_done;
+    const Map &d3 = maps.d3, &d2 = maps.d2, &d1 = maps.d1;
     // stage 4: cat(x4, ipt5) -> decoder_block4 -> gate (birefnet.rs:304-305, 323-329)
-    ipt_block(c, d.ipt[4], img, B, H, W, h4, w4, 3072, d4.window(3072, 384));
     Map p4 = new_map(c, B, h4, w4, 1536);
     decblk_forward(c, d.dec[0], d4, p4, dm);
     gdt_gate(c, d, 0, p4);
-    // stage 3 (birefnet.rs:332-344); ipt4_up is a same-size resize = identity
-    Map d3 = new_map(c, B, h3, w3, 1920);
-    run_resize(c, p4, d3.window(0, 1536));
-    run_gemm(c, d.lat[0], c.at(x3.p, x3.coff), B * h3 * w3, x3.ld, d3.p, d3.ld, 0, d3.p, d3.ld, 0);   // + lateral_block4(x3)
-    ipt_block(c, d.ipt[3], img, B, H, W, h3, w3, 768, d3.window(1536, 384));
+    // stage 3 (birefnet.rs:332-344)
+    if (lat_done) join_branches(c, 1u << AUX_LAT);
+    run_resize(c, p4, d3.window(0, 1536), lat_done);
+    if (!lat_done) run_gemm(c, d.lat[0], c.at(x3.p, x3.coff), B * h3 * w3, x3.ld, d3.p, d3.ld, 0, d3.p, d3.ld, 0);   // + lateral_block4(x3)
     Map p3 = new_map(c, B, h3, w3, 768);
     decblk_forward(c, d.dec[1], d3, p3, dm);
     gdt_gate(c, d, 1, p3);
     // stage 2 (birefnet.rs:347-359)
-    Map d2 = new_map(c, B, h2, w2, 960);
-    run_resize(c, p3, d2.window(0, 768));
-    run_gemm(c, d.lat[1], c.at(x2.p, x2.coff), B * h2 * w2, x2.ld, d2.p, d2.ld, 0, d2.p, d2.ld, 0);
-    ipt_block(c, d.ipt[2], img, B, H, W, h2, w2, 192, d2.window(768, 192));
+    run_resize(c, p3, d2.window(0, 768), lat_done);
+    if (!lat_done) run_gemm(c, d.lat[1], c.at(x2.p, x2.coff), B * h2 * w2, x2.ld, d2.p, d2.ld, 0, d2.p, d2.ld, 0);
     Map p2 = new_map(c, B, h2, w2, 384);
     decblk_forward(c, d.dec[2], d2, p2, dm);
     gdt_gate(c, d, 2, p2);
     // stage 1 (birefnet.rs:362-369)
-    // (bf16-storage mode: 512 channels, the last 32 zeros written by ipt_blk2's padded conv_out: decoder_block1.conv_in runs chunk-major)
-    const int d1pad = d.dec[3].conv_in.Cinp > 480 ? d.dec[3].conv_in.Cinp - 480 : 0;
-    Map d1 = new_map(c, B, h1, w1, 480 + d1pad);
-    d1.C = 480;
-    run_resize(c, p2, d1.window(0, 384));
-    run_gemm(c, d.lat[2], c.at(x1.p, x1.coff), B * h1 * w1, x1.ld, d1.p, d1.ld, 0, d1.p, d1.ld, 0);
-    if (d.ipt[1].conv_out.N != 96 + d1pad) fail(BRN_ERR_INVALID_ARG, "ipt_blk2 / decoder_block1 channel padding mismatch");
-    ipt_block(c, d.ipt[1], img, B, H, W, h1, w1, 48, d1.window(384, 96 + d1pad));
+    run_resize(c, p2, d1.window(0, 384), lat_done);
+    if (!lat_done) run_gemm(c, d.lat[2], c.at(x1.p, x1.coff), B * h1 * w1, x1.ld, d1.p, d1.ld, 0, d1.p, d1.ld, 0);
     Map p1 = new_map(c, B, h1, w1, 192);
     decblk_forward(c, d.dec[3], d1, p1, dm);
     // head (birefnet.rs:372-375): q = <p1, w[0:192]> at 1/4 res; t = the whole ipt_blk1 branch (conv1 -> conv_out -> its
@@ -556,7 +623,16 @@ void model_forward(Model& m, Ctx& c, const float* img, int B, int H, int W, floa
     // multi-scale concat targets (birefnet.rs:440-443) and the context concat (birefnet.rs:453): [x1|x2|x3|x4] at 1/32
     Map X1 = new_map(c, B, h1, w1, 384), X2 = new_map(c, B, h2, w2, 768), X3 = new_map(c, B, h3, w3, 1536);
     Map X4 = new_map(c, B, h4, w4, 5760);
+    Map D4 = new_map(c, B, h4, w4, 3456);
+    const DecMaps dmaps = alloc_dec_maps(c, m, B, H, W);
     stamp(0);
+    {
+        // the decoder's image-patch convolutions depend on nothing but the image: enqueued first, on an auxiliary stream, they fill
+        // the CUs the batch-1 backbone leaves idle (their temporaries stay allocated: the branch is joined in decoder_forward)
+        ArenaHold hold(*c.arena);
+        Branch br(c, AUX_IPT);
+        ipt_blocks(c, m, img, B, H, W, D4, dmaps);
+    }
     {
         // both backbone passes (birefnet.rs:416 and :426) as one pass over concatenated token rows
         const size_t mk2 = c.arena->mark();
@@ -584,12 +660,19 @@ void model_forward(Model& m, Ctx& c, const float* img, int B, int H, int W, floa
         run_resize(c, X2, X4.window(384, 768));
         run_resize(c, X3, X4.window(1152, 1536));
     }
+    DecMaps dmaps2 = dmaps;
+    if (!c.bf16) {
+        ArenaHold hold(*c.arena);
+        Branch br(c, AUX_LAT);
+        lateral_blocks(c, m, B, H, W, X1, X2, X3, dmaps2);
+        dmaps2.lat_done = true;
+    }
     stamp(2);
-    Map D4 = new_map(c, B, h4, w4, 3456);
     decblk_forward(c, m.squeeze, X4, D4.window(0, 3072), m.cfg.deform_mode);          // birefnet.rs:457
     stamp(3);
-    decoder_forward(c, m, img, B, H, W, X1, X2, X3, D4, out, apply_sigmoid);          // birefnet.rs:460
+    decoder_forward(c, m, img, B, H, W, X1, X2, X3, D4, out, apply_sigmoid, &dmaps2); // birefnet.rs:460
     stamp(4);
+    join_branches(c, ~0u);                 // (every branch is joined where its result is read; nothing may outlive the forward)
     c.arena->release(mk);
 }
 
@@ -601,6 +684,12 @@ Model::~Model() {
         if (sd.join_ev) (void)hipEventDestroy(sd.join_ev);
     }
     if (fork_ev) (void)hipEventDestroy(fork_ev);
+    for (BranchSet& bs : branch_sets)
+        for (int i = 0; i < BRN_AUX_STREAMS; ++i) {
+            if (bs.stream[i]) (void)hipStreamDestroy(bs.stream[i]);
+            if (bs.fork_ev[i]) (void)hipEventDestroy(bs.fork_ev[i]);
+            if (bs.join_ev[i]) (void)hipEventDestroy(bs.join_ev[i]);
+        }
     for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
     if (stage_ev_ok) for (int i = 0; i < 6; ++i) (void)hipEventDestroy(stage_ev[i]);
     if (done_ev) (void)hipEventDestroy(done_ev);

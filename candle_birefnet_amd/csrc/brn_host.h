@@ -49,7 +49,18 @@ struct Arena {
     float* alloc(size_t nfloats);
     float* alloc_bytes(size_t bytes) { return alloc((bytes + 3) / 4); }
     size_t mark() const { return top; }
-    void release(size_t m) { top = m; }
+    // hold > 0: nothing is handed out twice — the launches being enqueued run on several streams (graph branches), so "dead as soon
+    // as the next launch is enqueued" does not hold for scratch; the owner of the hold releases to its own mark afterwards
+    int hold = 0;
+    void release(size_t m) { if (!hold) top = m; }
+};
+
+// auxiliary streams of one forward: branches of the graph that do not depend on each other (the four ASPP branches of a decoder
+// block, the image-patch convolutions beside the backbone) are enqueued on them between a fork and a join event (brn_graph.cpp)
+constexpr int BRN_AUX_STREAMS = 5;   // 0-2: ASPP branches, 3: image-patch convolutions, 4: lateral convolutions
+struct BranchSet {
+    hipStream_t stream[BRN_AUX_STREAMS] = {};
+    hipEvent_t fork_ev[BRN_AUX_STREAMS] = {}, join_ev[BRN_AUX_STREAMS] = {};
 };
 
 struct Ctx {
@@ -62,6 +73,9 @@ struct Ctx {
     // compute mode BRN_BF16: activation maps are bf16 in HBM (esz = 2); pointers stay typed float* and are opaque to the host
     bool bf16 = false;
     int region = REGION_NONE;       // tag of the launches being recorded (profiling only)
+    BranchSet* br = nullptr;        // null: every branch stays on `stream` (profiled forwards, the op-level entry points)
+    unsigned pending = 0;           // branches enqueued on aux streams and not yet joined (bit k = aux stream k)
+    unsigned br_mask = ~0u;         // aux streams in use (bit k); BRN_BRANCH_STREAMS: 7 = ASPP branches, 8 = image-patch convs, 16 = laterals
     int esz() const { return bf16 ? 2 : 4; }
     float* act_alloc(size_t elems) { return arena->alloc_bytes(elems * (size_t)esz()); }
     template <class T> T* at(T* p, size_t elems) const { return reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(p)) + elems * (size_t)esz()); }
@@ -184,6 +198,7 @@ struct Model {
     // two half batches on two streams (run_model): second workspace, side stream, fork / join events
     struct Side { Arena arena; hipStream_t stream = nullptr; hipEvent_t join_ev = nullptr; };
     std::vector<Side> sides; hipEvent_t fork_ev = nullptr;
+    std::vector<BranchSet> branch_sets;   // one per sub-batch stream (run_model)
     bool profiling = false;
     bool bf16 = false;        // BRN_BF16: bf16 activations / weights in HBM
     std::vector<LaunchRecord> records;
@@ -224,7 +239,7 @@ void attach_deform_frags(DeviceOwner& own, GemmW& g, const float* w_oihw);
 void attach_dense_frags(DeviceOwner& own, GemmW& g, const float* w);
 void run_conv_nchw(Ctx& c, const GemmW& w, const float* x_nchw, int B, int Hin, int Win, const Map& out, bool pad_to_stride = false);
 void run_layernorm(Ctx& c, const LNW& ln, const float* x, int rows, int ldx, float* y, int ldy, int y_coff, int y_planes = 0, int y_bf16 = 0);
-void run_resize(Ctx& c, const Map& in, const Map& out);
+void run_resize(Ctx& c, const Map& in, const Map& out, bool accumulate = false);
 
 // SwinTransformer::forward (swin.rs:768-797): outs[i] are destination windows (stage outputs after norm_i)
 void swin_forward(Ctx& c, const SwinW& w, const float* img_nchw, int B, int H, int W, const Map outs[4]);
@@ -238,8 +253,11 @@ void swin_attention(Ctx& c, const SwinBlockW& blk, const float* xn, int B, int H
 void decblk_forward(Ctx& c, const DecBlkW& w, const Map& in, const Map& out, int deform_mode);
 // ASPPDeformable::forward (aspp.rs:303-333) on a 64-channel map t -> 64-channel map u (both whole maps: ld == C == 64)
 void aspp_forward(Ctx& c, const ASPPW& a, const Map& t, const Map& u, int deform_mode);
+// the decoder's concat maps (birefnet.rs:332,347,362) — allocated by the caller when the image-patch convolutions that fill their
+// last channels are enqueued early, beside the backbone (model_forward)
+struct DecMaps { Map d3, d2, d1; bool lat_done = false; };   // lat_done: lateral_block4/3/2 already wrote [0:C) of d3 / d2 / d1
 void decoder_forward(Ctx& c, const Model& m, const float* img_nchw, int B, int H, int W, const Map& x1, const Map& x2,
-                     const Map& x3, const Map& d4 /* [.., 3456] with [0:3072) = squeezed x4 */, float* out, int apply_sigmoid);
+                     const Map& x3, const Map& d4 /* [.., 3456] with [0:3072) = squeezed x4 */, float* out, int apply_sigmoid, const DecMaps* pre = nullptr);
 void model_forward(Model& m, Ctx& c, const float* img_nchw, int B, int H, int W, float* out, int apply_sigmoid);
 
 void ensure_device(int ordinal);

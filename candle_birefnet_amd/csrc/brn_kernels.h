@@ -118,7 +118,7 @@ hipError_t launch_window_attention2(const WindowAttnParams& p, const WindowAttnP
 // ---- data movement / elementwise (HBM-bound) ------------------------------------------------------------
 // bilinear, align_corners=true, channels-last window -> window; optional accumulate (y += )
 hipError_t launch_resize_nhwc(const float* x, int B, int Hin, int Win, int C, int ldx, int x_coff,
-                              float* y, int Hout, int Wout, int ldy, int y_coff, hipStream_t s, int bf16 = 0);
+                              float* y, int Hout, int Wout, int ldy, int y_coff, hipStream_t s, int bf16 = 0, int accumulate = 0);
 // NCHW planar bilinear (the 3-channel image -> half scale), align_corners=true
 hipError_t launch_resize_nchw(const float* x, int BC, int Hin, int Win, float* y, int Hout, int Wout, hipStream_t s);
 // NCHW -> NHWC window and back

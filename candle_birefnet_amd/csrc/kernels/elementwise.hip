@@ -42,7 +42,8 @@ __device__ __forceinline__ void ac_coord(int dst, int in, int out, int& i0, int&
 }
 
 // Tensor::upsample_bilinear2d(h, w, true) on a channels-last window (birefnet.rs:332,347,362,435-438,450-452)
-template <class T>
+// ACC: y += resize(x) (the decoder's lateral sums, birefnet.rs:333,348,363, when the lateral conv wrote y first)
+template <class T, bool ACC = false>
 __global__ void resize_nhwc_kernel(const T* __restrict__ x, int B, int Hin, int Win, int C4, int ldx, int x_coff,
                                    T* __restrict__ y, int Hout, int Wout, int ldy, int y_coff) {
     const size_t total = (size_t)B * Hout * Wout * C4;
@@ -62,8 +63,10 @@ __global__ void resize_nhwc_kernel(const T* __restrict__ x, int B, int Hin, int 
         const f32x4 v11 = ld4<T>(base + ((size_t)y1 * Win + x1) * ldx);
         const f32x4 top = v00 + (v01 - v00) * lx;
         const f32x4 bot = v10 + (v11 - v10) * lx;
-        const f32x4 r = top + (bot - top) * ly;
-        st4<T>(y + (((size_t)b * Hout + oy) * Wout + ox) * ldy + y_coff + c4 * 4, r);
+        f32x4 r = top + (bot - top) * ly;
+        T* yp = y + (((size_t)b * Hout + oy) * Wout + ox) * ldy + y_coff + c4 * 4;
+        if (ACC) r = ld4<T>(yp) + r;
+        st4<T>(yp, r);
     }
 }
 
@@ -98,8 +101,14 @@ __global__ void resize_nhwc_bf16x8_kernel(const __bf16* __restrict__ x, int B, i
 }
 
 hipError_t launch_resize_nhwc(const float* x, int B, int Hin, int Win, int C, int ldx, int x_coff,
-                              float* y, int Hout, int Wout, int ldy, int y_coff, hipStream_t s, int bf16) {
+                              float* y, int Hout, int Wout, int ldy, int y_coff, hipStream_t s, int bf16, int accumulate) {
     if (C % 4 || ldx % 4 || ldy % 4 || x_coff % 4 || y_coff % 4) return hipErrorInvalidValue;
+    if (accumulate) {                 // fp32 maps only: a bf16 sum of two rounded terms is not what the fused epilogue computes
+        if (bf16) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((resize_nhwc_kernel<float, true>), grid1d((size_t)B * Hout * Wout * (C / 4), 256), dim3(256), 0, s, x, B, Hin, Win, C / 4, ldx, x_coff,
+                           y, Hout, Wout, ldy, y_coff);
+        return hipGetLastError();
+    }
     const size_t total = (size_t)B * Hout * Wout * (C / 4);
     if (bf16 && ((C | ldx | ldy | x_coff | y_coff) & 7) == 0)
         hipLaunchKernelGGL(resize_nhwc_bf16x8_kernel, grid1d(total / 2, 256), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x), B, Hin, Win, C / 8,

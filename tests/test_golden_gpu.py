@@ -113,3 +113,41 @@ def test_bf16_modes_are_informational(gpu, mode, bound, tag):
     assert np.isfinite(y).all() and e < bound
     np.testing.assert_array_equal(m.forward_logits(x), y)
     m.close()
+
+
+@pytest.mark.parametrize("mode", ["f32_split3", "bf16"])
+def test_branch_streams_do_not_change_results(gpu, tmp_path, mode):
+    """Independent graph branches (the ASPP branches, the image-patch convolutions, the lateral convolutions) run on auxiliary
+    streams when the batch is one part (brn_graph.cpp: Branch).  Same kernels, same arguments: the logits must be bit-equal with
+    the streams off (BRN_BRANCH_STREAMS=0), on by default, and forced on for every class (31) — the switch is read once per
+    process, hence the child processes.  Batch 1 and 2, both deform modes, three forwards each (a forward reuses the workspace of
+    the previous one)."""
+    import subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import candle_birefnet_amd as cb, golden_cases as G\n"
+        "outs = {}\n"
+        "for tag in sorted(G.MODEL_CASES):\n"
+        "    cfg, w, x = G.model_case(tag)\n"
+        "    m = cb.BiRefNet.new(cfg, cb.VarBuilder.from_tensors(w), compute=%r)\n"
+        "    for xb in (x[:1], x[:2] if x.shape[0] > 1 else np.concatenate([x, x[:, :, ::-1]])):\n"
+        "        ys = [np.asarray(m.forward_logits(xb)) for _ in range(3)]\n"
+        "        assert all(np.array_equal(ys[0], y) for y in ys[1:]), tag\n"
+        "        outs[tag + '_b' + str(xb.shape[0])] = ys[0]\n"
+        "    m.close()\n"
+        "np.savez(sys.argv[1], **outs)\n") % (os.path.dirname(here), here, mode)
+    res = {}
+    for setting in ("0", "", "31"):
+        out = str(tmp_path / f"br{setting or 'default'}.npz")
+        env = dict(os.environ)
+        env.pop("BRN_BRANCH_STREAMS", None)
+        if setting:
+            env["BRN_BRANCH_STREAMS"] = setting
+        pr = subprocess.run([sys.executable, "-c", code, out], env=env, capture_output=True, text=True, timeout=900)
+        assert pr.returncode == 0, pr.stderr[-2000:]
+        res[setting] = np.load(out)
+    assert len(res["0"].files) >= 4
+    for k in res["0"].files:
+        np.testing.assert_array_equal(res["0"][k], res[""][k])
+        np.testing.assert_array_equal(res["0"][k], res["31"][k])
