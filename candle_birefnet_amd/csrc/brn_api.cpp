@@ -150,11 +150,25 @@ static void validate_config(const brn_config& c) {
         if (c.depths[i] < 1 || c.depths[i] > 64) fail(BRN_ERR_INVALID_ARG, "depths[%d]=%d out of range", i, c.depths[i]);
 }
 
+static void run_model_locked(Model* m, const float* x, int B, int H, int W, brn_mem in_loc, float* out, brn_mem out_loc, void* stream, int apply_sigmoid);
+
 static void run_model(Model* m, const float* x, int B, int H, int W, brn_mem in_loc, float* out, brn_mem out_loc, void* stream,
                       int apply_sigmoid) {
     if (!m || !x || !out) fail(BRN_ERR_INVALID_ARG, "null argument");
     if (B < 1) fail(BRN_ERR_INVALID_ARG, "batch must be >= 1");
     std::lock_guard<std::mutex> lk(m->mu);
+    try {
+        run_model_locked(m, x, B, H, W, in_loc, out, out_loc, stream, apply_sigmoid);
+    } catch (...) {
+        // a forward that failed half-way may have work in flight on its sub-batch / branch streams that no event of the next call
+        // orders against: drain the device before the workspace can be handed out again
+        (void)hipDeviceSynchronize();
+        throw;
+    }
+}
+
+static void run_model_locked(Model* m, const float* x, int B, int H, int W, brn_mem in_loc, float* out, brn_mem out_loc, void* stream,
+                             int apply_sigmoid) {
     BRN_HIP(hipSetDevice(m->device));
     hipStream_t s = (hipStream_t)stream;
     plan_model(*m, B, H, W);
