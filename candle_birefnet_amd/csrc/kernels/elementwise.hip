@@ -428,19 +428,24 @@ __global__ void __launch_bounds__(256) head_stencil5x5_kernel(const float* __res
     const float* kk = k + cs * 75;
     const float* xb = img + (size_t)b * 3 * H * W;
     float acc = bias[cs];
+    // all 75 loads go out unconditionally from clamped coordinates and a tap outside the image contributes a selected 0.0f
+    // (fmaf(0, k, acc) == acc: the same value as skipping it).  Skipping by `continue` put every load behind a lane-dependent
+    // branch; hipcc waits vmcnt(0) at each join, so a wave paid up to 25 memory round trips in a row (27 us per 1024^2 image).
 #pragma unroll
     for (int fy = 0; fy < 5; ++fy) {
         const int iy = oy + fy - 2;
-        if ((unsigned)iy >= (unsigned)H) continue;
+        const bool vy = (unsigned)iy < (unsigned)H;
+        const int iyc = min(max(iy, 0), H - 1);
 #pragma unroll
         for (int fx = 0; fx < 5; ++fx) {
             const int ix = ox + fx - 2;
-            if ((unsigned)ix >= (unsigned)W) continue;
-            const size_t o = (size_t)iy * W + ix;
+            const bool ok = vy && (unsigned)ix < (unsigned)W;
+            const size_t o = (size_t)iyc * W + min(max(ix, 0), W - 1);
             const float* kf = kk + (fy * 5 + fx) * 3;
-            acc = fmaf(xb[o], kf[0], acc);
-            acc = fmaf(xb[(size_t)H * W + o], kf[1], acc);
-            acc = fmaf(xb[2 * (size_t)H * W + o], kf[2], acc);
+            const float x0 = xb[o], x1 = xb[(size_t)H * W + o], x2 = xb[2 * (size_t)H * W + o];
+            acc = fmaf(ok ? x0 : 0.0f, kf[0], acc);
+            acc = fmaf(ok ? x1 : 0.0f, kf[1], acc);
+            acc = fmaf(ok ? x2 : 0.0f, kf[2], acc);
         }
     }
     y[((size_t)b * H + oy) * W + ox] = acc;
