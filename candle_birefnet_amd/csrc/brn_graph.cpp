@@ -99,8 +99,8 @@ static void run_gemm_bf16(Ctx& c, const GemmW& w, GemmParams& p, int fam) {
     c.arena->release(mk);
     if (c.dry) return;
     p.Wp = w.wb; p.wp_rows = w.wb_rows; p.wp_ld = w.wb_ld; p.planes = 1;
-    static const bool wstat_off = getenv("BRN_WSTAT") && atoi(getenv("BRN_WSTAT")) == 0;
-    if (w.wf && w.mode == GEMM_DENSE && !wstat_off) {          // short K, wide A: the weights stay in registers (gemm_wstat_bf16_kernel)
+    static const int wstat_mask = getenv("BRN_WSTAT") ? atoi(getenv("BRN_WSTAT")) : 3;       // bit 0: K = 192, bit 1: K = 384
+    if (w.wf && w.mode == GEMM_DENSE && (wstat_mask & (p.K == 384 ? 2 : 1))) {   // short K, wide A: the weights stay in registers (gemm_wstat_bf16_kernel)
         GemmParams q = p;
         q.Wp = w.wf;
         if (gemm_wstat_eligible(q)) {

@@ -193,7 +193,7 @@ void attach_deform_frags(DeviceOwner& own, GemmW& g, const float* w) {
 }
 
 void attach_dense_frags(DeviceOwner& own, GemmW& g, const float* w) {
-    if (g_build_planes != BUILD_BF16 || g.mode != GEMM_DENSE || g.K != 192 || g.N < 192 || g.N % 192) return;
+    if (g_build_planes != BUILD_BF16 || g.mode != GEMM_DENSE || (g.K != 192 && g.K != 384) || g.N < 192 || g.N % 192) return;
     const int k32 = g.K / 32, nb_n = g.N / 16;
     std::vector<uint16_t> wf((size_t)nb_n * k32 * 64 * 8, 0);
     for (int n = 0; n < g.N; ++n)

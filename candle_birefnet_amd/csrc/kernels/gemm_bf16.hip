@@ -697,10 +697,14 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
 // =====================================================================================================================
 __device__ __forceinline__ int ws_slot(int r, int c) { return (r >> 1) * 256 + (((((r & 1) << 3) | c) ^ ((r >> 1) & 15)) << 4); }
 
-template <int KS, int ACT>
+// WBM = rows per A tile: 64 at K = 192 (two 24-KB buffers), 32 at K = 384 (the W slice is 144 VGPRs there; two 24-KB buffers again,
+// so two workgroups still share a CU and one's epilogue overlaps the other's MFMAs)
+template <int KS, int ACT, int WBM = 64>
 __global__ void __launch_bounds__(256, 2) gemm_wstat_bf16_kernel(const GemmParams p) {
-    constexpr int WBM = 64, WBN = 192, SUB = WBM * 128;                 // rows per tile, columns per workgroup, bytes of one K step's sub-tile
+    constexpr int WBN = 192, SUB = WBM * 128;                            // columns per workgroup, bytes of one K step's sub-tile
     constexpr int K32 = KS * 2, ABUF = KS * SUB;
+    constexpr int NJ = WBM / 32, RF = WBM / 16;                          // LDS-DMA instructions per wave and K step, 16-row fragments per tile
+    static_assert(WBM == 64 || WBM == 32, "tile rows");
     static_assert(ABUF >= 32 * 512, "a 32-row half of the C tile (512-byte rows) must fit the A buffer it replaces");
     __shared__ __attribute__((aligned(1024))) char smem[2 * ABUF];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -724,11 +728,11 @@ __global__ void __launch_bounds__(256, 2) gemm_wstat_bf16_kernel(const GemmParam
     f32x4_b bias[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) bias[j] = p.bias ? *reinterpret_cast<const f32x4_b*>(p.bias + n0 + 16 * j + 4 * (lane >> 4)) : zero4b();
-    // ---- this lane's share of an A tile: LDS-DMA instruction ii = wave + 4 j (j = 0, 1) of every sub-tile fills bank rows 4 ii .. 4 ii + 3 ----
-    unsigned a_voff[2];
-    int a_row[2];
+    // ---- this lane's share of an A tile: LDS-DMA instruction ii = wave + 4 j (j < NJ) of every sub-tile fills bank rows 4 ii .. 4 ii + 3 ----
+    unsigned a_voff[NJ];
+    int a_row[NJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int pr = 4 * (wave + 4 * j) + (lane >> 4), qs = (lane & 15) ^ (pr & 15);
         a_row[j] = 2 * pr + (qs >> 3);
         a_voff[j] = (unsigned)((qs & 7) * 16);                          // byte offset inside the 128-byte K-step piece of the row
@@ -738,15 +742,15 @@ __global__ void __launch_bounds__(256, 2) gemm_wstat_bf16_kernel(const GemmParam
         const int m0 = t * WBM;
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Ab + (long)m0 * p.lda + p.a_coff), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const unsigned ro = (unsigned)((min(m0 + a_row[j], p.M - 1) - m0) * p.lda * 2) + a_voff[j];   // rows >= M re-read row M - 1 (never stored)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) blds16(rs, ro, ks * 128, buf + ks * SUB + (wave + 4 * j) * 1024);
         }
     };
-    int a_foff[4][2];
+    int a_foff[RF][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RF; ++i)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) a_foff[i][s2] = ws_slot(16 * i + (lane & 15), 4 * s2 + (lane >> 4));
 
@@ -755,30 +759,30 @@ __global__ void __launch_bounds__(256, 2) gemm_wstat_bf16_kernel(const GemmParam
     for (int it = 0; t < t_hi; ++it, t += nw) {
         char* buf = smem + (it & 1) * ABUF;
         const bool more = t + nw < t_hi;
-        if (more) { issue(t + nw, smem + ((it + 1) & 1) * ABUF); wait_vmcnt<2 * KS>(); }   // this tile (and the previous tile's stores) landed; the next one may be in flight
+        if (more) { issue(t + nw, smem + ((it + 1) & 1) * ABUF); wait_vmcnt<NJ * KS>(); }   // this tile (and the previous tile's stores) landed; the next one may be in flight
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        f32x4_b acc[4][3];
+        f32x4_b acc[RF][3];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < RF; ++i)
 #pragma unroll
             for (int j = 0; j < 3; ++j) acc[i][j] = zero4b();
 #pragma unroll
         for (int ks = 0; ks < K32; ++ks) {
-            bf16x8 af[4];
+            bf16x8 af[RF];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(buf + (ks >> 1) * SUB + a_foff[i][ks & 1]);
+            for (int i = 0; i < RF; ++i) af[i] = *reinterpret_cast<const bf16x8*>(buf + (ks >> 1) * SUB + a_foff[i][ks & 1]);
 #pragma unroll
             for (int j = 0; j < 3; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[j][ks], af[i], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < RF; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[j][ks], af[i], acc[i][j], 0, 0, 0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                   // every wave has read its fragments: the buffer now takes the C tile
         const int m0 = t * WBM;
         __bf16* Cb = reinterpret_cast<__bf16*>(p.C);
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int half = 0; half < WBM / 32; ++half) {
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii) {
                 const int i = 2 * half + ii, row = 16 * ii + (lane & 15);          // row within the 32-row half
@@ -812,7 +816,7 @@ __global__ void __launch_bounds__(256, 2) gemm_wstat_bf16_kernel(const GemmParam
 
 constexpr int WSTAT_WG_PER_CU = 2;      // 2: <= 256 VGPRs, no spill (forced to 168 for three per CU the kernel spills 30-40 registers)
 bool gemm_wstat_eligible(const GemmParams& p) {
-    return p.mode == GEMM_DENSE && p.Wp && (p.K == 192) && p.N >= 192 && (p.N % 192) == 0 && !p.c_f32 && !p.R && !p.scale && !p.bbias &&
+    return p.mode == GEMM_DENSE && p.Wp && (p.K == 192 || p.K == 384) && p.N >= 192 && (p.N % 192) == 0 && !p.c_f32 && !p.R && !p.scale && !p.bbias &&
            ((p.lda | p.a_coff | p.ldc | p.c_coff) & 7) == 0 && p.M >= 32768 && (long)p.lda * 2 * 64 < 0x7fffffffL;
 }
 hipError_t launch_gemm_wstat(const GemmParams& p, hipStream_t s) {
@@ -820,6 +824,12 @@ hipError_t launch_gemm_wstat(const GemmParams& p, hipStream_t s) {
     const int G = p.N / 192;
     const int nw = (256 * WSTAT_WG_PER_CU / 8) / G;
     dim3 grid(8 * G * nw), block(256);
+    if (p.K == 384) {
+        if (p.act == ACT_GELU_ERF) hipLaunchKernelGGL((gemm_wstat_bf16_kernel<6, ACT_GELU_ERF, 32>), grid, block, 0, s, p);
+        else if (p.act == ACT_RELU) hipLaunchKernelGGL((gemm_wstat_bf16_kernel<6, ACT_RELU, 32>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((gemm_wstat_bf16_kernel<6, ACT_NONE, 32>), grid, block, 0, s, p);
+        return hipGetLastError();
+    }
     if (p.act == ACT_GELU_ERF) hipLaunchKernelGGL((gemm_wstat_bf16_kernel<3, ACT_GELU_ERF>), grid, block, 0, s, p);
     else if (p.act == ACT_RELU) hipLaunchKernelGGL((gemm_wstat_bf16_kernel<3, ACT_RELU>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((gemm_wstat_bf16_kernel<3, ACT_NONE>), grid, block, 0, s, p);

@@ -387,13 +387,13 @@ def test_window_attention_bf16_two_heads_per_workgroup(gpu, tmp_path):
         np.testing.assert_array_equal(res["1"][k], res["2"][k])
 
 
-@pytest.mark.parametrize("H,W,O,act", [(192, 192, 576, None), (181, 183, 768, "gelu_erf"), (192, 171, 192, "relu"), (256, 256, 1152, "gelu_erf")])
-def test_short_k_weight_stationary_gemm_bf16_mode(gpu, H, W, O, act):
-    """gemm_wstat_bf16_kernel (K = 192, N % 192 == 0, M >= 32768: the stage-0 qkv / fc1 GEMMs at batch >= 4) through a 1x1 conv on a
-    bf16 map: full and ragged row tiles (M % 64 != 0), 1 / 3 / 4 / 6 column groups, bias, GELU / ReLU.  Exact-operand reference;
-    the output map is bf16: one bf16 ulp (+ the 3-term erfc's 2.6e-5 for GELU)."""
+@pytest.mark.parametrize("C,H,W,O,act", [(192, 192, 192, 576, None), (192, 181, 183, 768, "gelu_erf"), (192, 192, 171, 192, "relu"), (192, 256, 256, 1152, "gelu_erf"),
+                                         (384, 192, 192, 1152, None), (384, 181, 183, 1536, "gelu_erf"), (384, 192, 171, 384, "relu"), (384, 200, 203, 192, None)])
+def test_short_k_weight_stationary_gemm_bf16_mode(gpu, C, H, W, O, act):
+    """gemm_wstat_bf16_kernel (K = 192 with 64-row tiles, K = 384 with 32-row tiles; N % 192 == 0, M >= 32768: the stage-0 / stage-1
+    qkv and fc1 GEMMs at batch >= 4) through a 1x1 conv on a bf16 map: full and ragged row tiles (M % 64, M % 32 != 0), 1 ... 8 column
+    groups, bias, GELU / ReLU.  Exact-operand reference; the output map is bf16: one bf16 ulp (+ the 3-term erfc's 2.6e-5 for GELU)."""
     from candle_birefnet_amd import ops
-    C = 192
     x, w, b = rnd(1, C, H, W, seed=1), rnd(O, C, 1, 1, seed=2, std=C ** -0.5), rnd(O, seed=3, std=0.1)
     ops.set_compute("bf16")
     try:
