@@ -14,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 D=gpurun_out/prof_${SUF}
 rm -rf $D && mkdir -p $D
 B="python3 bench.py --config $CFG --cpu-baseline off --also= --profile-steps 0 --other-configs off ${DEFORM:+--deform-mode deformable}"
-export BRN_SPLIT_STREAMS=1
+export BRN_SPLIT_STREAMS=1 BRN_BRANCH_STREAMS=0   # one stream, no auxiliary branch streams: kernels run alone
 rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -- $B --steps 3 --warmup 1 > $D/stats.log 2>&1
 echo "[profile] stats done"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $D/fetch -- $B --steps 1 --warmup 0 > $D/fetch.log 2>&1
@@ -27,7 +27,7 @@ BRN_DUMP_LAUNCHES=$D/launches.csv python3 bench.py --config $CFG --cpu-baseline 
 python3 tools/make_profiles.py --tag $TAG --suffix $SUF --stats $D/stats --fetch $D/fetch --write $D/write --launches $D/launches.csv --forwards 4
 python3 tools/pmc_sq_summary.py $D/sq profiles/${TAG}_pmc_sq_${SUF}.csv
 if [ "$CFG" != "c2" ]; then
-  export BRN_SPLIT_STREAMS=2
+  export BRN_SPLIT_STREAMS=2; unset BRN_BRANCH_STREAMS
   rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats2 -- $B --steps 3 --warmup 1 > $D/stats2.log 2>&1
   python3 tools/make_profiles.py --tag $TAG --suffix 2streams_$SUF --stats $D/stats2 --forwards 4
   rm -rf $D/stats2
