@@ -301,10 +301,32 @@ void swin_stage_dims(int H, int W, int patch, int hs[4], int ws[4]) {
     }
 }
 
+// proj + residual + the block's second LayerNorm in one launch (gemm_wstat_ln_bf16_kernel: compute mode BRN_BF16, C = 192, M >= 32768);
+// false = not applicable, nothing enqueued (no workspace is involved either way, so a dry run and a real run agree trivially)
+static bool run_gemm_ln(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* x, const LNW& ln, float* y, int ldy) {
+    static const bool off = getenv("BRN_WSTAT_LN") && atoi(getenv("BRN_WSTAT_LN")) == 0;
+    if (!c.bf16 || off || !w.wf || w.mode != GEMM_DENSE || ln.C != w.N || !ln.g || !ln.b) return false;
+    GemmParams p{};
+    p.A = A; p.C = x; p.M = M; p.N = w.N; p.K = w.K; p.mode = GEMM_DENSE; p.lda = lda;
+    p.bias = w.bias; p.scale = w.scale; p.shift = w.shift; p.act = w.act;
+    p.R = x; p.ldr = w.N; p.ldc = w.N; p.c_f32 = 1; p.r_f32 = 1;
+    p.Wp = w.wf; p.planes = 1;
+    if (!gemm_wstat_ln_eligible(p)) return false;
+    if (c.dry) return true;
+    const double flop = 2.0 * M * (double)w.N * w.K;
+    const double bytes = 2.0 * ((double)M * w.K + (double)w.N * w.K) + (4.0 + 4.0 + 2.0) * (double)M * w.N;
+    Bracket b(c, FAM_GEMM_DENSE, flop, bytes, M, w.N, w.K);
+    BRN_LAUNCH(launch_gemm_wstat_ln(p, ln.g, ln.b, 1e-5f, y, ldy, c.stream));
+    return true;
+}
+
 // The attention half of a block for `nin` token sets that share the weights (the full- and half-scale backbone passes
 // of birefnet.rs:416,426 are run as ONE pass over concatenated token rows: every per-token op sees M = M_full + M_half).
-static void swin_attention_multi(Ctx& c, const SwinBlockW& blk, const float* xn, int B, int nin, const int* hs, const int* wsz, int C,
-                                 int shift, float* y, const float* residual, int p2 = 0, int window = 12) {
+// ln2 / xn2: the block's norm2 and its output matrix — when the projection can take the LayerNorm into its epilogue (run_gemm_ln)
+// it is done here and the function returns true.
+static bool swin_attention_multi(Ctx& c, const SwinBlockW& blk, const float* xn, int B, int nin, const int* hs, const int* wsz, int C,
+                                 int shift, float* y, const float* residual, int p2 = 0, int window = 12, const LNW* ln2 = nullptr,
+                                 float* xn2 = nullptr, int ld_xn2 = 0) {
     const size_t mk = c.arena->mark();
     int M = 0;
     for (int k = 0; k < nin; ++k) M += B * hs[k] * wsz[k];
@@ -335,8 +357,11 @@ static void swin_attention_multi(Ctx& c, const SwinBlockW& blk, const float* xn,
         BRN_LAUNCH(launch_window_attention2(ps[0], nin > 1 ? &ps[1] : nullptr, c.stream));
     }
     // swin.rs:310 (+ shortcut, swin.rs:406); the residual stream y / residual stays fp32 in every mode
-    run_gemm(c, blk.proj, att, M, ldp, y, C, 0, residual, C, 0, nullptr, 0, p2, 0, c.bf16, c.bf16);
+    bool ln_done = false;
+    if (ln2 && xn2 && !p2 && y == residual) ln_done = run_gemm_ln(c, blk.proj, att, M, ldp, y, *ln2, xn2, ld_xn2);
+    if (!ln_done) run_gemm(c, blk.proj, att, M, ldp, y, C, 0, residual, C, 0, nullptr, 0, p2, 0, c.bf16, c.bf16);
     c.arena->release(mk);
+    return ln_done;
 }
 
 void swin_attention(Ctx& c, const SwinBlockW& blk, const float* xn, int B, int H, int W, int C, int shift, float* y,
@@ -401,8 +426,8 @@ void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int 
             // would split out while staging), so the GEMMs' staging waves only copy
             const int p2 = stage_pl;
             run_layernorm(c, bk.norm1, x, M, C, xn, ldx, 0, p2, yb);                  // swin.rs:355
-            swin_attention_multi(c, bk, xn, B, nin, hh, ww, C, shift, x, x, p2, w.window);   // x = shortcut + attn (swin.rs:406)
-            run_layernorm(c, bk.norm2, x, M, C, xn, ldx, 0, p2, yb);                  // swin.rs:407
+            const bool ln2_done = swin_attention_multi(c, bk, xn, B, nin, hh, ww, C, shift, x, x, p2, w.window, &bk.norm2, xn, ldx);   // x = shortcut + attn (swin.rs:406)
+            if (!ln2_done) run_layernorm(c, bk.norm2, x, M, C, xn, ldx, 0, p2, yb);   // swin.rs:407
             run_gemm(c, bk.fc1, xn, M, ldx, hid, ldh, 0, nullptr, 0, 0, nullptr, 0, p2, p2);   // fc1 + gelu_erf (swin.rs:104-105)
             run_gemm(c, bk.fc2, hid, M, ldh, x, C, 0, x, C, 0, nullptr, 0, p2, 0, yb, yb);     // x + fc2(...) (swin.rs:106,407)
         }

@@ -65,6 +65,10 @@ hipError_t launch_gemm_bf16(const GemmParams& p, const GemmPlan& plan, float* ws
 // MFMA fragment order (GemmW::wf, attach_dense_frags), K = 192, N % 192 == 0, bf16 out, bias + activation only
 bool gemm_wstat_eligible(const GemmParams& p);
 hipError_t launch_gemm_wstat(const GemmParams& p, hipStream_t s);
+// the same with N = K = 192, fp32 C + fp32 residual (in place or not) AND y = LayerNorm(C) gamma + beta written as a bf16 matrix
+// (gemm_wstat_ln_bf16_kernel: the attention projection of a C = 192 stage with the block's norm2 in its epilogue)
+bool gemm_wstat_ln_eligible(const GemmParams& p);
+hipError_t launch_gemm_wstat_ln(const GemmParams& p, const float* gamma, const float* beta, float eps, void* y_bf16, int ldy, hipStream_t s);
 
 // bf16-storage mode, modulated deformable conv (kernels/deform_bf16.hip): A = bf16 channels-last map, om = fp32 offsets | modulator,
 // Wp = the weights in MFMA fragment order (GemmW::wf), C = bf16 window.  eligible(): shapes the kernel covers (else gemm_f32_kernel)

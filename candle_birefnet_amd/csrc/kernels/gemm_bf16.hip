@@ -814,6 +814,158 @@ __global__ void __launch_bounds__(256, 2) gemm_wstat_bf16_kernel(const GemmParam
     }
 }
 
+// =====================================================================================================================
+// gemm_wstat_ln_bf16_kernel — the attention output projection of a C = 192 stage with the block's second LayerNorm in its epilogue
+// (swin.rs:310,406,407): x = A Wᵀ + bias + x (fp32 residual stream, in place) and y = LayerNorm(x) γ + β (bf16, the fc1 operand).
+// N = K = 192: a workgroup of the weight-stationary kernel above owns WHOLE rows (4 waves x 48 columns), so the row statistics are
+// local.  The C tile goes through the A buffer as fp32 (32 rows x 768 B = the 24-KB buffer, 16-byte chunks XOR-ed with the row); on the
+// way back 8 lanes share a row (6 chunks each): residual add, store of x, two-pass mean / biased variance (the arithmetic of
+// layernorm_kernel) over the 8 lanes by DPP shuffles, store of y.  What it saves is the stand-alone LayerNorm's read of x.
+// =====================================================================================================================
+__global__ void __launch_bounds__(256, 2) gemm_wstat_ln_bf16_kernel(const GemmParams p, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                     const float eps, __bf16* __restrict__ Y, const int ldy) {
+    constexpr int KS = 3, WBM = 64, WBN = 192, SUB = WBM * 128;
+    constexpr int K32 = KS * 2, ABUF = KS * SUB;
+    static_assert(ABUF == 32 * WBN * 4, "a 32-row half of the fp32 C tile is exactly one A buffer");
+    __shared__ __attribute__((aligned(1024))) char smem[2 * ABUF];
+    __shared__ __attribute__((aligned(16))) float gb_s[2 * WBN];         // gamma | beta
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = (p.M + WBM - 1) / WBM;
+    const int xcd = blockIdx.x & 7, wk = blockIdx.x >> 3, nw = (int)gridDim.x >> 3;
+    const int t_lo = (int)((long)T * xcd / 8), t_hi = (int)((long)T * (xcd + 1) / 8);
+    if (tid < WBN) { gb_s[tid] = gamma[tid]; gb_s[WBN + tid] = beta[tid]; }
+    const int n0 = wave * 48;
+    bf16x8 wfr[3][K32];
+    {
+        const char* wf = reinterpret_cast<const char*>(p.Wp) + ((long)(n0 >> 4) * K32 * 64 + lane) * 16;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int ks = 0; ks < K32; ++ks) wfr[j][ks] = *reinterpret_cast<const bf16x8*>(wf + (long)(j * K32 + ks) * 1024);
+    }
+    f32x4_b bias[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) bias[j] = p.bias ? *reinterpret_cast<const f32x4_b*>(p.bias + n0 + 16 * j + 4 * (lane >> 4)) : zero4b();
+    unsigned a_voff[2];
+    int a_row[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pr = 4 * (wave + 4 * j) + (lane >> 4), qs = (lane & 15) ^ (pr & 15);
+        a_row[j] = 2 * pr + (qs >> 3);
+        a_voff[j] = (unsigned)((qs & 7) * 16);
+    }
+    const __bf16* Ab = reinterpret_cast<const __bf16*>(p.A);
+    auto issue = [&](int t, char* buf) {
+        const int m0 = t * WBM;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Ab + (long)m0 * p.lda + p.a_coff), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned ro = (unsigned)((min(m0 + a_row[j], p.M - 1) - m0) * p.lda * 2) + a_voff[j];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) blds16(rs, ro, ks * 128, buf + ks * SUB + (wave + 4 * j) * 1024);
+        }
+    };
+    int a_foff[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) a_foff[i][s2] = ws_slot(16 * i + (lane & 15), 4 * s2 + (lane >> 4));
+    const int er = tid >> 3, ec = tid & 7;                               // read-back: row of the 32-row half, first chunk (then + 8 k)
+    float* Cf = reinterpret_cast<float*>(p.C);
+    const float* Rf = reinterpret_cast<const float*>(p.R);
+
+    int t = t_lo + wk;
+    if (t < t_hi) issue(t, smem);
+    for (int it = 0; t < t_hi; ++it, t += nw) {
+        char* buf = smem + (it & 1) * ABUF;
+        const bool more = t + nw < t_hi;
+        if (more) { issue(t + nw, smem + ((it + 1) & 1) * ABUF); wait_vmcnt<2 * KS>(); }
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        f32x4_b acc[4][3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[i][j] = zero4b();
+#pragma unroll
+        for (int ks = 0; ks < K32; ++ks) {
+            bf16x8 af[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(buf + (ks >> 1) * SUB + a_foff[i][ks & 1]);
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[j][ks], af[i], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                   // every wave has read its fragments: the buffer now takes the C tile
+        const int m0 = t * WBM;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int m = m0 + half * 32 + er, mc = min(m, p.M - 1);
+            f32x4_b rr[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) rr[k] = *reinterpret_cast<const f32x4_b*>(Rf + (long)mc * p.ldr + p.r_coff + (ec + 8 * k) * 4);
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = 2 * half + ii, row = 16 * ii + (lane & 15);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int ch = (wave * 48 + 16 * j + 4 * (lane >> 4)) >> 2;      // 16-byte chunk of the 768-byte row
+                    *reinterpret_cast<f32x4_b*>(buf + row * 768 + ((ch ^ (row & 7)) << 4)) = acc[i][j] + bias[j];
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            f32x4_b xv[6];
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int ch = ec + 8 * k;
+                xv[k] = *reinterpret_cast<const f32x4_b*>(buf + er * 768 + ((ch ^ (er & 7)) << 4)) + rr[k];
+                sum += (xv[k][0] + xv[k][1]) + (xv[k][2] + xv[k][3]);
+            }
+            if (m < p.M) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) *reinterpret_cast<f32x4_b*>(Cf + (long)m * p.ldc + p.c_coff + (ec + 8 * k) * 4) = xv[k];
+            }
+            sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
+            const float mean = sum / (float)WBN;
+            float sq = 0.f;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                xv[k] = xv[k] - mean;
+                sq += (xv[k][0] * xv[k][0] + xv[k][1] * xv[k][1]) + (xv[k][2] * xv[k][2] + xv[k][3] * xv[k][3]);
+            }
+            sq += __shfl_xor(sq, 1); sq += __shfl_xor(sq, 2); sq += __shfl_xor(sq, 4);
+            const float rstd = 1.0f / sqrtf(sq / (float)WBN + eps);
+            if (m < p.M) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const int c0 = (ec + 8 * k) * 4;
+                    const f32x4_b gm = *reinterpret_cast<const f32x4_b*>(gb_s + c0), bt = *reinterpret_cast<const f32x4_b*>(gb_s + WBN + c0);
+                    const f32x4_b o = xv[k] * rstd * gm + bt;
+                    const u32x2_b ob = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+                    *reinterpret_cast<u32x2_b*>(Y + (long)m * ldy + c0) = ob;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                               // the half (and, after the second one, the buffer) is free again
+        }
+    }
+}
+bool gemm_wstat_ln_eligible(const GemmParams& p) {
+    return p.mode == GEMM_DENSE && p.Wp && p.K == 192 && p.N == 192 && p.c_f32 && p.R && p.r_f32 && !p.scale && !p.bbias && p.act == ACT_NONE &&
+           ((p.lda | p.a_coff) & 7) == 0 && ((p.ldc | p.c_coff | p.ldr | p.r_coff) & 3) == 0 && p.M >= 32768 && (long)p.lda * 2 * 64 < 0x7fffffffL;
+}
+hipError_t launch_gemm_wstat_ln(const GemmParams& p, const float* gamma, const float* beta, float eps, void* y_bf16, int ldy, hipStream_t s) {
+    if (!gemm_wstat_ln_eligible(p) || !gamma || !beta || !y_bf16 || (ldy & 3)) return hipErrorInvalidValue;
+    dim3 grid(8 * (256 * 2 / 8)), block(256);
+    hipLaunchKernelGGL(gemm_wstat_ln_bf16_kernel, grid, block, 0, s, p, gamma, beta, eps, reinterpret_cast<__bf16*>(y_bf16), ldy);
+    return hipGetLastError();
+}
+
 constexpr int WSTAT_WG_PER_CU = 2;      // 2: <= 256 VGPRs, no spill (forced to 168 for three per CU the kernel spills 30-40 registers)
 bool gemm_wstat_eligible(const GemmParams& p) {
     return p.mode == GEMM_DENSE && p.Wp && (p.K == 192 || p.K == 384) && p.N >= 192 && (p.N % 192) == 0 && !p.c_f32 && !p.R && !p.scale && !p.bbias &&
