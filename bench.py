@@ -96,8 +96,8 @@ def cpu_torch_worker(size, deform_mode):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=15)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS), help="BASELINE.json configuration (sets batch, size, compute)")
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (overrides --config)")
     ap.add_argument("--size", type=int, default=0, help="image side (overrides --config)")
