@@ -115,7 +115,10 @@ static void run_gemm_bf16(Ctx& c, const GemmW& w, GemmParams& p, int fam) {
     const double a_elems = p.mode == GEMM_DENSE ? (double)p.M * p.K : (double)p.M / ((double)p.Hout * p.Wout) * p.Hin * p.Win * p.Cin;
     const double bytes = 2.0 * (a_elems + (double)p.N * p.K) + (p.c_f32 ? 4.0 : 2.0) * (double)p.M * p.N + (p.R ? (p.r_f32 ? 4.0 : 2.0) * (double)p.M * p.N : 0.0);
     Bracket b(c, fam, flop, bytes, p.M, p.N, p.K);
-    BRN_LAUNCH(launch_gemm_bf16(p, pl, ws, c.stream));
+    const hipError_t e = launch_gemm_bf16(p, pl, ws, c.stream);
+    if (e != hipSuccess)
+        fail(BRN_ERR_HIP, "launch_gemm_bf16 (M %d, N %d, K %d, mode %d, Cin %d, %d x %d -> %d x %d, lda %d + %d, ldc %d + %d, tile cfg %d, split-K %d, chunk-major %d): %s",
+             p.M, p.N, p.K, p.mode, p.Cin, p.Hin, p.Win, p.Hout, p.Wout, p.lda, p.a_coff, p.ldc, p.c_coff, pl.cfg, pl.splitk, p.k_chunk_major, hipGetErrorString(e));
 }
 
 void run_gemm(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* C, int ldc, int c_coff, const float* R, int ldr,

@@ -1046,6 +1046,9 @@ GemmPlan plan_gemm_bf16(int M, int N, int K, bool f32_residual, bool gelu) {
     long best_tiles = 1;
     for (const Bf16Cfg& c : kBf16Cfgs) {
         const long tiles = (long)((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn);
+        // W rows are padded to multiples of 256 (brn_weights.cpp): a 192-wide tile grid must not reach past that padding (N = 512
+        // would need 576 rows; found at 1056 x 1056, where M = 17424 made 256 x 192 the cheapest tile for the ASPP 1 x 1 pair)
+        if ((N + c.bn - 1) / c.bn * c.bn > (N + 255) / 256 * 256) continue;
         // a launch lasts ~ rounds x (tile area x workgroups sharing a CU) / relative CU throughput of the config
         double eff = K > 1536 ? c.eff_long_k : c.eff;
         // (f32_residual — proj / fc2 — is a hint without effect for now: two workgroups per CU measured 4 % faster in isolation on

@@ -182,3 +182,45 @@ def test_bench_two_ranks_reports_c4_blocks(gpu):
         assert blk["outputs_finite"] and blk["max_abs_err_image0_vs_strided_golden"] < BF16_ABS_BOUND["bf16"]
         assert blk["deform_mode"] == ("deformable" if k.endswith("deformable") else "reference_cpu")
         assert blk["roofline"]["families"]["gemm_deform_nhwc"]["launches"] == (20 if k.endswith("deformable") else 0)
+
+
+def test_bf16_ragged_token_count_against_oracle(gpu):
+    """1056 x 1056 (33 x 33 patches of 32): the stage-0 token count, 264^2 + 132^2 = 87120, is not a multiple of the 64-row tiles of the
+    weight-stationary kernels (gemm_wstat_bf16_kernel for qkv / fc1, gemm_wstat_ln_bf16_kernel = projection + norm2 in one launch),
+    the maps are padded to the window size at every stage, and the window grid has a ragged border.  Mode bf16 against the fp32 CPU
+    oracle on the same input (test infrastructure, ~10 s): bounded like the other bf16 runs; the call repeated is bit-identical."""
+    import torch
+    from oracle import oracle as O
+    cb, m = _full_model("bf16", 1, 1056)
+    x = cb.synth_input(1, 1056, 1056)
+    xd = torch.from_numpy(x).cuda()
+    y = m.forward_logits(xd)
+    assert torch.equal(y, m.forward_logits(xd))
+    cfg = cb.BiRefNetConfig()
+    w = cb.synth_weights(cb.birefnet_weight_spec(cfg), seed=42)
+    ref = np.asarray(O.forward_logits(O.cfg_from(cfg), w, x), np.float64)
+    err = float(np.abs(y.cpu().numpy().astype(np.float64) - ref).max())
+    print(f"1056x1056 Swin-L [bf16]: max abs err vs the fp32 oracle {err:.3e} (|logit| max {np.abs(ref).max():.2f})")
+    assert np.isfinite(err) and err < BF16_ABS_BOUND["bf16"]
+    m.close()
+
+
+@pytest.mark.parametrize("deform", ["reference_cpu", "deformable"])
+def test_odd_sizes_and_batches_bf16_tracks_fp32_equivalent(gpu, deform):
+    """Sizes and batches the tile planners never saw while being tuned (non-square, odd patch-grid sides, batches 1 ... 5; token
+    counts that are not multiples of any tile): every launch must be accepted — a 1056 x 1056 input once made the bf16 planner pick
+    a 192-wide tile grid that reached past the padding of a 512-row weight matrix — and mode bf16 must stay within its bound of the
+    parity-graded f32_split3 on the same input.  (tools/size_sweep.py is the longer list.)"""
+    import torch
+    import candle_birefnet_amd as cb
+    cfg = cb.BiRefNetConfig(deform_mode=deform)
+    w = cb.synth_weights(cb.birefnet_weight_spec(cfg), seed=42)
+    ms = {mode: cb.BiRefNet.new(cfg, cb.VarBuilder.from_tensors(w), compute=mode) for mode in ("f32_split3", "bf16")}
+    for H, W, B in [(608, 608, 1), (736, 864, 2), (1184, 1056, 1), (672, 672, 5), (416, 1760, 3)]:
+        x = torch.from_numpy(cb.synth_input(B, H, W)).cuda()
+        ys = {k: m.forward_logits(x).float().cpu().numpy() for k, m in ms.items()}
+        assert all(np.isfinite(v).all() for v in ys.values()), (H, W, B)
+        d = float(np.abs(ys["bf16"] - ys["f32_split3"]).max())
+        assert d < BF16_ABS_BOUND["bf16"], (H, W, B, d)
+    for m in ms.values():
+        m.close()
