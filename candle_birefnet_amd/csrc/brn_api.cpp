@@ -14,6 +14,7 @@ const char* last_error_cstr();
 template <class F>
 static brn_status guarded(F&& f) {
     try {
+        (void)hipGetLastError();              // an error another library (or an earlier failed call) left in this thread is not ours to report
         f();
         return BRN_OK;
     } catch (const Error& e) {
@@ -92,23 +93,36 @@ static void with_arena(hipStream_t s, const std::function<void(Ctx&)>& fn, bool 
     (void)hipFree(d);
 }
 
+// Size the workspace for a (B, H, W) request: a dry run of the forward with a counting arena.  Every request shape is planned
+// on its own and the workspace only grows to the largest need seen (batch 16 at 512^2 followed by batch 1 at 2080^2 must not
+// reserve batch 16 at 2080^2); a request that is <= a planned shape in every dimension fits without a new dry run.
 static void plan_model(Model& m, int B, int H, int W) {
-    if (B <= m.plan_B && H <= m.plan_H && W <= m.plan_W && m.arena.base) return;
-    const int pb = B > m.plan_B ? B : m.plan_B, ph = H > m.plan_H ? H : m.plan_H, pw = W > m.plan_W ? W : m.plan_W;
+    if (m.arena.base)
+        for (const Model::Planned& q : m.planned)
+            if (B <= q.B && H <= q.H && W <= q.W) return;
     Arena dry;
     dry.dry = true;
     Ctx c{&dry, nullptr, true, false, nullptr, nullptr, nullptr};
     c.bf16 = m.bf16;
-    model_forward(m, c, nullptr, pb, ph, pw, nullptr, 0);
+    model_forward(m, c, nullptr, B, H, W, nullptr, 0);
     size_t need = dry.peak + 4096;
     // staging for host-resident input / output of the full model
-    need += ((size_t)pb * 3 * ph * pw + (size_t)pb * ph * pw) * sizeof(float) + 1024;
-    if (m.arena.base) { BRN_HIP(hipDeviceSynchronize()); (void)hipFree(m.arena.base); m.arena.base = nullptr; }
-    void* d = nullptr;
-    hipError_t e = hipMalloc(&d, need);
-    if (e != hipSuccess) fail(BRN_ERR_OOM, "workspace hipMalloc of %zu bytes (B=%d, %dx%d) failed: %s", need, pb, ph, pw, hipGetErrorString(e));
-    m.arena.base = (char*)d; m.arena.cap = need; m.arena.top = 0; m.arena.peak = 0; m.arena.dry = false;
-    m.plan_B = pb; m.plan_H = ph; m.plan_W = pw;
+    need += ((size_t)B * 3 * H * W + (size_t)B * H * W) * sizeof(float) + 1024;
+    if (!m.arena.base || need > m.arena.cap) {
+        if (m.arena.base) { BRN_HIP(hipDeviceSynchronize()); (void)hipFree(m.arena.base); m.arena.base = nullptr; m.arena.cap = 0; m.planned.clear(); }
+        void* d = nullptr;
+        hipError_t e = hipMalloc(&d, need);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();          // (the failed allocation must not be reported again by the next launch check)
+            fail(BRN_ERR_OOM, "workspace hipMalloc of %zu bytes (B=%d, %dx%d) failed: %s", need, B, H, W, hipGetErrorString(e));
+        }
+        m.arena.base = (char*)d; m.arena.cap = need; m.arena.top = 0; m.arena.peak = 0; m.arena.dry = false;
+    }
+    if (m.planned.size() >= 16) m.planned.erase(m.planned.begin());
+    m.planned.push_back({B, H, W});
+    if (B > m.plan_B) m.plan_B = B;
+    if (H > m.plan_H) m.plan_H = H;
+    if (W > m.plan_W) m.plan_W = W;
 }
 
 static void collect_profile(Model& m, hipStream_t s) {

@@ -190,7 +190,9 @@ struct Model {
     DecoderW dec;
     bool has_decoder = false;
     Arena arena;
-    int plan_B = 0, plan_H = 0, plan_W = 0;
+    int plan_B = 0, plan_H = 0, plan_W = 0;   // the largest request planned last (a request <= it in every dimension fits)
+    struct Planned { int B, H, W; };
+    std::vector<Planned> planned;             // shapes known to fit the workspace (requests are planned one by one, not as the product of the maxima)
     std::mutex mu;            // forward calls on one handle are serialised (one workspace)
     // the workspace is reused by every forward: a call on a different stream than the previous one first waits (on the GPU)
     // for the previous forward's last kernel, so two streams never overlap inside the arena
