@@ -169,3 +169,25 @@ def test_two_handles_from_two_threads(gpu):
     assert not errs, errs
     for m in ms:
         m.close()
+
+
+@pytest.mark.parametrize("compute,tol", [("f32_split3", 2e-4), ("f32_split2", 1e-3), ("bf16", 3e-2)])
+@pytest.mark.parametrize("deform", ["reference_cpu", "deformable"])
+def test_pieces_in_every_compute_mode(gpu, compute, tol, deform):
+    """backbone / squeeze_module / decoder driven one by one (bench_inference.rs:37-92) in the other compute modes, batch 2 at a
+    non-square size, against the fp64 torch restatement (tools/pieces_probe.py is the longer list): relative bound per mode."""
+    import candle_birefnet_amd as cb
+    cfg = cb.BiRefNetConfig(deform_mode=deform)
+    cfg.swin.depths = [2, 2, 2, 2]
+    w = cb.synth_weights(cb.birefnet_weight_spec(cfg), seed=42)
+    x = cb.synth_input(2, 160, 224)
+    ref, parts = R.forward_logits(x, w, cfg, torch.float64, return_parts=True)
+    m = cb.BiRefNet.new(cfg, cb.VarBuilder.from_tensors(w), compute=compute)
+    for a, b in zip(m.backbone.forward(x), parts["f"]):
+        assert a.shape == tuple(b.shape)
+        assert np.abs(a - b.numpy()).max() <= tol * max(1.0, float(b.abs().max()))
+    x4s = m.squeeze_module.forward(parts["x4"].float().numpy())
+    assert np.abs(x4s - parts["x4s"].numpy()).max() <= tol * max(1.0, float(parts["x4s"].abs().max()))
+    out = m.decoder.forward(x, *[parts[k].float().numpy() for k in ("x1", "x2", "x3", "x4s")])
+    assert np.abs(out - ref.numpy()).max() <= tol * max(1.0, float(ref.abs().max()))
+    m.close()
