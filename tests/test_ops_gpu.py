@@ -433,3 +433,13 @@ def test_op_level_shape_fuzz(gpu):
     pr = subprocess.run([sys.executable, os.path.join(root, "tools", "op_fuzz.py"), "50", "11"], capture_output=True, text=True, timeout=900)
     assert pr.returncode == 0, pr.stderr[-2000:]
     assert "50 cases, 0 problems" in pr.stdout, pr.stdout[-3000:]
+
+
+def test_window_attention_geometry_fuzz(gpu):
+    """tools/att_fuzz.py: 30 random (batch, H, W, heads, shift) geometries through the op-level window attention in each compute mode
+    (maps from 1 x 1 to 49 x 49: pad tokens, ragged window grids, shifted and not) against the fp64 torch restatement."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pr = subprocess.run([sys.executable, os.path.join(root, "tools", "att_fuzz.py"), "30", "5"], capture_output=True, text=True, timeout=900)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    assert "30 cases, 0 problems" in pr.stdout, pr.stdout[-3000:]
