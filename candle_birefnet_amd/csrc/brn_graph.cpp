@@ -382,7 +382,25 @@ void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int 
     const int E = w.embed_dim;
     // PatchEmbed (swin.rs:692-714): conv k4 s4 straight from the NCHW image (zero beyond the border = pad_with_zeros), LN
     float* x = c.arena->alloc((size_t)total(0) * E);
-    {
+    // compute mode BRN_BF16, Swin-L geometry, image sides multiples of 4: conv + bias + LayerNorm in one kernel per image scale
+    // (kernels/patch_embed.hip) — neither the conv output nor a second pass over it touches HBM
+    static const bool pe_off = getenv("BRN_PATCH_LN") && atoi(getenv("BRN_PATCH_LN")) == 0;
+    bool pe_fused = c.bf16 && !pe_off && w.patch_proj.w && w.patch_proj.mode == GEMM_GATHER_NCHW && w.patch_proj.pad == 0 && w.patch_proj.dil == 1 &&
+                    w.patch_proj.kh == w.patch_proj.kw && w.patch_norm.C == E && w.patch_norm.g && w.patch_norm.b;
+    for (int k = 0; k < nin && pe_fused; ++k)
+        pe_fused = patch_embed_ln_eligible(w.patch_proj.Cin, w.patch_proj.N, w.patch_proj.kh, w.patch_proj.stride, ins[k].H, ins[k].W, w.patch_proj.K, E);
+    if (pe_fused) {
+        size_t off = 0;
+        for (int k = 0; k < nin; ++k) {
+            if (!c.dry) {
+                const double M = (double)rows(k, 0);
+                Bracket b(c, FAM_GEMM_GATHER, 2.0 * M * E * w.patch_proj.Kreal, 4.0 * ((double)B * 3 * ins[k].H * ins[k].W + M * E), (int)M, E, w.patch_proj.K);
+                BRN_LAUNCH(launch_patch_embed_ln(ins[k].img, B, ins[k].H, ins[k].W, w.patch_proj.w, w.patch_proj.K, w.patch_proj.bias, w.patch_norm.g,
+                                                 w.patch_norm.b, 1e-5f, x + off * E, E, c.stream));
+            }
+            off += rows(k, 0);
+        }
+    } else {
         const size_t mk = c.arena->mark();
         float* t = c.arena->alloc((size_t)total(0) * E);
         size_t off = 0;

@@ -67,6 +67,11 @@ bool gemm_wstat_eligible(const GemmParams& p);
 hipError_t launch_gemm_wstat(const GemmParams& p, hipStream_t s);
 // the same with N = K = 192, fp32 C + fp32 residual (in place or not) AND y = LayerNorm(C) gamma + beta written as a bf16 matrix
 // (gemm_wstat_ln_bf16_kernel: the attention projection of a C = 192 stage with the block's norm2 in its epilogue)
+// PatchEmbed for the Swin-L geometry as one kernel (kernels/patch_embed.hip): 4 x 4 stride-4 conv of the NCHW image (3 -> 192) + bias +
+// LayerNorm, fp32, written into the residual stream x [B * H/4 * W/4][ldx]
+bool patch_embed_ln_eligible(int Cin, int N, int k, int stride, int H, int W, int ldw, int ldx);
+hipError_t launch_patch_embed_ln(const float* img, int B, int H, int W, const float* wgt, int ldw, const float* bias, const float* gamma,
+                                 const float* beta, float eps, float* x, int ldx, hipStream_t s);
 bool gemm_wstat_ln_eligible(const GemmParams& p);
 hipError_t launch_gemm_wstat_ln(const GemmParams& p, const float* gamma, const float* beta, float eps, void* y_bf16, int ldy, hipStream_t s);
 
