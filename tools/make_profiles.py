@@ -76,7 +76,7 @@ def main():
                 n = len(fe[k][0]); f_kb = fe[k][1]; w_kb = wr.get(k, [set(), 0.0])[1]
                 rgb, wgb = 2 * f_kb * 1024 / 1e9, w_kb * 1024 / 1e9
                 w.writerow([k, n, f"{f_kb:.1f}", f"{w_kb:.1f}", f"{rgb:.3f}", f"{wgb:.3f}"])
-                if "gemm" in k and "reduce" not in k:
+                if ("gemm" in k or "patch_embed" in k) and "reduce" not in k:      # (patch_embed_ln_kernel is bracketed as the gather GEMM it replaces)
                     gem["gemm_family_dispatches"] += n; gem["hbm_read_gb_x2corrected"] += rgb; gem["hbm_write_gb"] += wgb
         json.dump(gem, open(os.path.join(root, f"{a.tag}_gemm_traffic_{a.suffix}.json"), "w"))
         print("wrote", out, gem)
