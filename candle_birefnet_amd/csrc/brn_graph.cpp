@@ -384,19 +384,27 @@ void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int 
     float* x = c.arena->alloc((size_t)total(0) * E);
     // compute mode BRN_BF16, Swin-L geometry, image sides multiples of 4: conv + bias + LayerNorm in one kernel per image scale
     // (kernels/patch_embed.hip) — neither the conv output nor a second pass over it touches HBM
-    static const bool pe_off = getenv("BRN_PATCH_LN") && atoi(getenv("BRN_PATCH_LN")) == 0;
+    static const int pe_env = getenv("BRN_PATCH_LN") ? atoi(getenv("BRN_PATCH_LN")) : 1;     // 0: two kernels; 2: fused without the first block's norm1
+    const bool pe_off = pe_env == 0;
     bool pe_fused = c.bf16 && !pe_off && w.patch_proj.w && w.patch_proj.mode == GEMM_GATHER_NCHW && w.patch_proj.pad == 0 && w.patch_proj.dil == 1 &&
                     w.patch_proj.kh == w.patch_proj.kw && w.patch_norm.C == E && w.patch_norm.g && w.patch_norm.b;
     for (int k = 0; k < nin && pe_fused; ++k)
         pe_fused = patch_embed_ln_eligible(w.patch_proj.Cin, w.patch_proj.N, w.patch_proj.kh, w.patch_proj.stride, ins[k].H, ins[k].W, w.patch_proj.K, E);
+    // ... and, while the row is in registers, the first block's norm1 of it (the bf16 operand of that block's qkv GEMM)
+    float* xn0 = nullptr;
+    if (pe_fused && pe_env != 2 && !w.stages[0].blocks.empty() && w.stages[0].C == E && w.stages[0].blocks[0].norm1.C == E && w.stages[0].blocks[0].norm1.g &&
+        w.stages[0].blocks[0].norm1.b)
+        xn0 = c.act_alloc((size_t)total(0) * E);
     if (pe_fused) {
         size_t off = 0;
         for (int k = 0; k < nin; ++k) {
             if (!c.dry) {
                 const double M = (double)rows(k, 0);
-                Bracket b(c, FAM_GEMM_GATHER, 2.0 * M * E * w.patch_proj.Kreal, 4.0 * ((double)B * 3 * ins[k].H * ins[k].W + M * E), (int)M, E, w.patch_proj.K);
+                Bracket b(c, FAM_GEMM_GATHER, 2.0 * M * E * w.patch_proj.Kreal, 4.0 * ((double)B * 3 * ins[k].H * ins[k].W + M * E) + (xn0 ? 2.0 * M * E : 0.0), (int)M, E, w.patch_proj.K);
+                const LNW* n1 = xn0 ? &w.stages[0].blocks[0].norm1 : nullptr;
                 BRN_LAUNCH(launch_patch_embed_ln(ins[k].img, B, ins[k].H, ins[k].W, w.patch_proj.w, w.patch_proj.K, w.patch_proj.bias, w.patch_norm.g,
-                                                 w.patch_norm.b, 1e-5f, x + off * E, E, c.stream));
+                                                 w.patch_norm.b, 1e-5f, x + off * E, E, c.stream, n1 ? n1->g : nullptr, n1 ? n1->b : nullptr,
+                                                 xn0 ? c.at(xn0, off * E) : nullptr, E));
             }
             off += rows(k, 0);
         }
@@ -438,7 +446,8 @@ void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int 
         const int ldx = stage_pl ? C * stage_pl / 2 : C, ldh = stage_pl ? hidden * stage_pl / 2 : hidden;
         // compute mode BRN_BF16: x (the residual stream) stays fp32; every GEMM operand (xn, qkv, att, hid, pm) is bf16
         const int yb = c.bf16;
-        float* xn = c.act_alloc((size_t)M * ldx);
+        const bool xn_ready = i == 0 && xn0 && !stage_pl && ldx == C;     // block 0's norm1 came out of the PatchEmbed kernel
+        float* xn = xn_ready ? xn0 : c.act_alloc((size_t)M * ldx);
         float* hid = c.act_alloc((size_t)M * ldh);
         for (size_t j = 0; j < st.blocks.size(); ++j) {
             const SwinBlockW& bk = st.blocks[j];
@@ -446,7 +455,7 @@ void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int 
             // split modes: every GEMM input of the block is written by its producer in the P layout (the bf16 planes the GEMM
             // would split out while staging), so the GEMMs' staging waves only copy
             const int p2 = stage_pl;
-            run_layernorm(c, bk.norm1, x, M, C, xn, ldx, 0, p2, yb);                  // swin.rs:355
+            if (!(xn_ready && j == 0)) run_layernorm(c, bk.norm1, x, M, C, xn, ldx, 0, p2, yb);   // swin.rs:355
             const bool ln2_done = swin_attention_multi(c, bk, xn, B, nin, hh, ww, C, shift, x, x, p2, w.window, &bk.norm2, xn, ldx);   // x = shortcut + attn (swin.rs:406)
             if (!ln2_done) run_layernorm(c, bk.norm2, x, M, C, xn, ldx, 0, p2, yb);   // swin.rs:407
             run_gemm(c, bk.fc1, xn, M, ldx, hid, ldh, 0, nullptr, 0, 0, nullptr, 0, p2, p2);   // fc1 + gelu_erf (swin.rs:104-105)

@@ -71,7 +71,8 @@ hipError_t launch_gemm_wstat(const GemmParams& p, hipStream_t s);
 // LayerNorm, fp32, written into the residual stream x [B * H/4 * W/4][ldx]
 bool patch_embed_ln_eligible(int Cin, int N, int k, int stride, int H, int W, int ldw, int ldx);
 hipError_t launch_patch_embed_ln(const float* img, int B, int H, int W, const float* wgt, int ldw, const float* bias, const float* gamma,
-                                 const float* beta, float eps, float* x, int ldx, hipStream_t s);
+                                 const float* beta, float eps, float* x, int ldx, hipStream_t s, const float* gamma1 = nullptr,
+                                 const float* beta1 = nullptr, void* xn_bf16 = nullptr, int ldxn = 0);   // (gamma1 / beta1 / xn: also LayerNorm(x) gamma1 + beta1 as a bf16 matrix)
 bool gemm_wstat_ln_eligible(const GemmParams& p);
 hipError_t launch_gemm_wstat_ln(const GemmParams& p, const float* gamma, const float* beta, float eps, void* y_bf16, int ldy, hipStream_t s);
 

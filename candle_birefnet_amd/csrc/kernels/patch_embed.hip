@@ -3,7 +3,8 @@
 // stream.  A workgroup owns whole rows (4 waves x 48 output channels), so the row statistics are local and neither the conv output
 // nor a second pass over it touches HBM: image in (12 B per pixel), x out (768 B per token).  fp32 operands on
 // v_mfma_f32_16x16x4_f32 (the flops are nothing: 18 KFLOP per token), fp32 accumulation, the arithmetic of layernorm_kernel
-// (two-pass mean / biased variance) on the row.  Used in compute mode BRN_BF16, where the two launches it replaces (gather GEMM +
+// (two-pass mean / biased variance) on the row; optionally the first block's norm1 of that row too (bf16, the qkv operand).
+// Used in compute mode BRN_BF16, where the two launches it replaces (gather GEMM +
 // LayerNorm) cost 0.5 ms per 8-image step; the fp32 modes keep their own kernels.
 #include "../brn_kernels.h"
 
@@ -16,16 +17,20 @@ constexpr int PE_N = 192, PE_K = 48, PE_TM = 64, PE_LDA = 52;            // chan
 __global__ void __launch_bounds__(256, 2) patch_embed_ln_kernel(const float* __restrict__ img, const int B, const int H, const int W,
                                                                 const float* __restrict__ wgt, const int ldw, const float* __restrict__ bias,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, const float eps,
-                                                                float* __restrict__ x, const int ldx, const int img_aligned16) {
+                                                                float* __restrict__ x, const int ldx, const int img_aligned16,
+                                                                const float* __restrict__ gamma1, const float* __restrict__ beta1, void* __restrict__ xn, const int ldxn) {
     __shared__ __attribute__((aligned(16))) float As[PE_TM * PE_LDA];    // [token][k = (c, ky, kx)]
     __shared__ __attribute__((aligned(16))) float Cs[32 * PE_N];         // a 32-row half of the C tile, 16-byte chunks XOR-ed with the row
-    __shared__ __attribute__((aligned(16))) float gb_s[2 * PE_N];
+    __shared__ __attribute__((aligned(16))) float gb_s[4 * PE_N];        // gamma | beta of PatchEmbed's norm, then of the first block's norm1 (optional)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
     const int Hp = H >> 2, Wp = W >> 2;
     const long M = (long)B * Hp * Wp;
     const int T = (int)((M + PE_TM - 1) / PE_TM);
-    if (tid < PE_N) { gb_s[tid] = gamma[tid]; gb_s[PE_N + tid] = beta[tid]; }
+    if (tid < PE_N) {
+        gb_s[tid] = gamma[tid]; gb_s[PE_N + tid] = beta[tid];
+        if (xn) { gb_s[2 * PE_N + tid] = gamma1[tid]; gb_s[3 * PE_N + tid] = beta1[tid]; }
+    }
     // this wave's 48 columns of W as MFMA A operands: lane (n = 16 j + li, k = 4 ks + g)
     float wfr[3][12];
 #pragma unroll
@@ -111,12 +116,39 @@ __global__ void __launch_bounds__(256, 2) patch_embed_ln_kernel(const float* __r
             }
             sq += __shfl_xor(sq, 1); sq += __shfl_xor(sq, 2); sq += __shfl_xor(sq, 4);
             const float rstd = 1.0f / sqrtf(sq / (float)PE_N + eps);
-            if (m < M) {
+            float sum1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int c0 = (ec + 8 * k) * 4;
+                const f32x4_p gm = *reinterpret_cast<const f32x4_p*>(gb_s + c0), bt = *reinterpret_cast<const f32x4_p*>(gb_s + PE_N + c0);
+                xv[k] = xv[k] * rstd * gm + bt;
+                if (m < M) *reinterpret_cast<f32x4_p*>(x + m * ldx + c0) = xv[k];
+                sum1 += (xv[k][0] + xv[k][1]) + (xv[k][2] + xv[k][3]);
+            }
+            if (xn) {
+                // the first block's norm1 (swin.rs:355) of the row just written, as the bf16 operand of its qkv GEMM: the row is still in registers
+                sum1 += __shfl_xor(sum1, 1); sum1 += __shfl_xor(sum1, 2); sum1 += __shfl_xor(sum1, 4);
+                const float mean1 = sum1 / (float)PE_N;
+                float sq1 = 0.f;
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
-                    const int c0 = (ec + 8 * k) * 4;
-                    const f32x4_p gm = *reinterpret_cast<const f32x4_p*>(gb_s + c0), bt = *reinterpret_cast<const f32x4_p*>(gb_s + PE_N + c0);
-                    *reinterpret_cast<f32x4_p*>(x + m * ldx + c0) = xv[k] * rstd * gm + bt;
+                    xv[k] = xv[k] - mean1;
+                    sq1 += (xv[k][0] * xv[k][0] + xv[k][1] * xv[k][1]) + (xv[k][2] * xv[k][2] + xv[k][3] * xv[k][3]);
+                }
+                sq1 += __shfl_xor(sq1, 1); sq1 += __shfl_xor(sq1, 2); sq1 += __shfl_xor(sq1, 4);
+                const float rstd1 = 1.0f / sqrtf(sq1 / (float)PE_N + eps);
+                if (m < M) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        const int c0 = (ec + 8 * k) * 4;
+                        const f32x4_p gm = *reinterpret_cast<const f32x4_p*>(gb_s + 2 * PE_N + c0), bt = *reinterpret_cast<const f32x4_p*>(gb_s + 3 * PE_N + c0);
+                        const f32x4_p o = xv[k] * rstd1 * gm + bt;
+                        typedef __bf16 bf16x4_p __attribute__((ext_vector_type(4)));
+                        bf16x4_p h;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) h[e] = (__bf16)o[e];
+                        *reinterpret_cast<bf16x4_p*>(reinterpret_cast<__bf16*>(xn) + m * ldxn + c0) = h;
+                    }
                 }
             }
         }
@@ -127,14 +159,16 @@ bool patch_embed_ln_eligible(int Cin, int N, int k, int stride, int H, int W, in
     return Cin == 3 && N == PE_N && k == 4 && stride == 4 && H >= 4 && W >= 4 && (H & 3) == 0 && (W & 3) == 0 && ldw >= PE_K && (ldx & 3) == 0;
 }
 hipError_t launch_patch_embed_ln(const float* img, int B, int H, int W, const float* wgt, int ldw, const float* bias, const float* gamma,
-                                 const float* beta, float eps, float* x, int ldx, hipStream_t s) {
+                                 const float* beta, float eps, float* x, int ldx, hipStream_t s, const float* gamma1, const float* beta1,
+                                 void* xn_bf16, int ldxn) {
     if (!patch_embed_ln_eligible(3, PE_N, 4, 4, H, W, ldw, ldx) || B <= 0 || !img || !wgt || !gamma || !beta || !x) return hipErrorInvalidValue;
     if (reinterpret_cast<uintptr_t>(x) & 15) return hipErrorInvalidValue;
+    if (xn_bf16 && (!gamma1 || !beta1 || (ldxn & 3) || (reinterpret_cast<uintptr_t>(xn_bf16) & 7))) return hipErrorInvalidValue;
     const int img_aligned16 = (reinterpret_cast<uintptr_t>(img) & 15) == 0;
     const long M = (long)B * (H >> 2) * (W >> 2);
     long tiles = (M + PE_TM - 1) / PE_TM;
     const int grid = (int)(tiles < 1024 ? tiles : 1024);
-    hipLaunchKernelGGL(patch_embed_ln_kernel, dim3(grid), dim3(256), 0, s, img, B, H, W, wgt, ldw, bias, gamma, beta, eps, x, ldx, img_aligned16);
+    hipLaunchKernelGGL(patch_embed_ln_kernel, dim3(grid), dim3(256), 0, s, img, B, H, W, wgt, ldw, bias, gamma, beta, eps, x, ldx, img_aligned16, gamma1, beta1, xn_bf16, ldxn);
     return hipGetLastError();
 }
 
