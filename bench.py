@@ -150,6 +150,22 @@ def streams_used(batch):
     return max(1, min(max(1, min(want, 8)), batch // 2))
 
 
+def branch_streams_used(batch):
+    """auxiliary streams for independent graph branches inside one forward (brn_graph.cpp: Branch; BRN_BRANCH_STREAMS): by default on
+    (5 streams: ASPP branches, image-patch convs, lateral convs) when the batch runs as one part, off with sub-batch streams"""
+    env = os.environ.get("BRN_BRANCH_STREAMS")
+    if env is not None:
+        try:
+            mask = int(env)
+        except ValueError:
+            mask = -1
+        if mask == 0:
+            return 0
+        if mask > 0:
+            return bin(mask & 31).count("1")
+    return 5 if streams_used(batch) == 1 else 0
+
+
 def golden_error(y, S, deform_mode):
     """max |y[0] - golden| on the committed strided golden of image 0 (seed 1000) for this geometry and deform mode
     (tests/golden/make_golden.py: fp64 torch restatement at 1024^2, fp32 at 2048^2), or None when there is none"""
@@ -437,7 +453,7 @@ def main(argv=None):
                 blk = {"workload": olabel + (f"; that per-GPU workload on each of {world} ranks" if world > 1 else ""),
                        "images_per_s": round(ips, 3), "ms_per_step": round(t_o / OTHER_STEPS * 1e3, 3), "steps": OTHER_STEPS, "warmup": OTHER_WARMUP,
                        "n_gpus": world, "batch_per_gpu": oB, "size": oS, "dtype": MODES[omode][1], "compute": omode, "deform_mode": dm,
-                       "streams_per_gpu": streams_used(oB),
+                       "streams_per_gpu": streams_used(oB), "branch_streams_per_gpu": branch_streams_used(oB),
                        "outputs_finite": bool(torch.isfinite(y_o).all().item()),
                        "reference_gflop_per_image": round(g_ref, 1),
                        "whole_step_frac_of_mode_peak": round(ips / world * g_ref / 1e3 / PEAK_BF16_MFMA_TFLOPS, 4),
@@ -466,7 +482,7 @@ def main(argv=None):
             "vs_baseline": None, "dtype": MODES[compute][1], "data": "synthetic",
             "config": {"workload": workload, "baseline_config": None if custom else args.config,
                        "batch_per_gpu": B, "global_batch": B * world, "size": S, "deform_mode": args.deform_mode,
-                       "compute": compute, "streams_per_gpu": streams_used(B),
+                       "compute": compute, "streams_per_gpu": streams_used(B), "branch_streams_per_gpu": branch_streams_used(B),
                        "parallelism": f"{world} replica(s), batch-sharded (candle_birefnet_amd.shard.shard_range), no data-path collective",
                        "inputs": "resident in HBM (torch cuda tensors), weights: synthetic seed 42"},
             "outputs_finite": finite,
