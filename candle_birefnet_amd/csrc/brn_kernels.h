@@ -62,7 +62,7 @@ GemmPlan plan_gemm_bf16(int M, int N, int K, bool f32_residual = false, bool gel
 hipError_t launch_gemm_bf16(const GemmParams& p, const GemmPlan& plan, float* ws, hipStream_t s);
 
 // bf16-storage mode, short-K dense GEMM with the weights resident in registers (kernels/gemm_bf16.hip, gemm_wstat_bf16_kernel): Wp = the weights in
-// MFMA fragment order (GemmW::wf, attach_dense_frags), K = 192, N % 192 == 0, bf16 out, bias + activation only
+// MFMA fragment order (GemmW::wf, attach_dense_frags), K = 192 (64-row A tiles) or 384 (32-row tiles), N % 192 == 0, bf16 out, bias + activation only
 bool gemm_wstat_eligible(const GemmParams& p);
 hipError_t launch_gemm_wstat(const GemmParams& p, hipStream_t s);
 // the same with N = K = 192, fp32 C + fp32 residual (in place or not) AND y = LayerNorm(C) gamma + beta written as a bf16 matrix

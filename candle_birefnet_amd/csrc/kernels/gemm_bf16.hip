@@ -685,8 +685,8 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
 
 
 // =====================================================================================================================
-// gemm_wstat_bf16_kernel — dense C = act(A W^T + b) for SHORT K (K = 64 KS <= 192) and wide A (M >> N): the stage-0 qkv / fc1 GEMMs of
-// the Swin backbone at batch >= 4 (swin.rs:98,130; M = 655 360, K = 192, N = 576 / 768 at batch 8).  With three K steps per tile the
+// gemm_wstat_bf16_kernel — dense C = act(A W^T + b) for SHORT K (K = 64 KS: 192, or 384 with 32-row tiles) and wide A (M >> N): the stage-0 /
+// stage-1 qkv and fc1 GEMMs of the Swin backbone at batch >= 4 (swin.rs:98,130; M = 655 360, K = 192, N = 576 / 768 at batch 8).  With three K steps per tile the
 // persistent 256 x 256 kernel above is prologue / epilogue all the way (2.0 - 2.6 TB/s of algorithmic traffic); here the weights never
 // move: a wave keeps its 48 columns of W (K x 48 bf16 = 72 VGPRs, loaded once, stored in MFMA fragment order by attach_dense_frags) for
 // the whole launch and the workgroup streams 64-row tiles of A through a two-buffer LDS ring (LDS-DMA, XOR-swizzled 128-byte rows as
