@@ -443,3 +443,13 @@ def test_window_attention_geometry_fuzz(gpu):
     pr = subprocess.run([sys.executable, os.path.join(root, "tools", "att_fuzz.py"), "30", "5"], capture_output=True, text=True, timeout=900)
     assert pr.returncode == 0, pr.stderr[-2000:]
     assert "30 cases, 0 problems" in pr.stdout, pr.stdout[-3000:]
+
+
+def test_deform_conv2d_geometry_fuzz(gpu):
+    """tools/deform_fuzz.py: 25 random DeformableConv2d geometries (32 ... 128 input channels, 1 / 3 / 7 taps, stride 1 / 2, padded or not,
+    ragged maps, batch 1 ... 3) in both deform modes and each compute mode against the fp64 torch restatement."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pr = subprocess.run([sys.executable, os.path.join(root, "tools", "deform_fuzz.py"), "25", "3"], capture_output=True, text=True, timeout=900)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    assert "25 cases, 0 problems" in pr.stdout, pr.stdout[-3000:]

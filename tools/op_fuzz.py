@@ -22,7 +22,7 @@ for it in range(n):
         b = rng.standard_normal(O, dtype=np.float32) * 0.1 if rng.random() < 0.7 else None
         desc = f"conv B{B} Cin{Cin} {H}x{W} O{O} k{k} s{s} p{pad} d{dil} act={act} bias={b is not None}"
     else:
-        M = int(rng.choice([1, 7, 64, 100, 144, 1000, 4097, 20000])); K = int(rng.choice([32, 64, 96, 192, 384, 768, 1000 // 32 * 32, 3072])); N = int(rng.choice([1, 16, 64, 100, 192, 384, 576, 768, 1000]))
+        M = int(rng.choice([1, 7, 64, 100, 144, 1000, 4097, 20000, 40000, 70001])); K = int(rng.choice([32, 64, 96, 192, 384, 768, 1000 // 32 * 32, 3072])); N = int(rng.choice([1, 16, 64, 100, 192, 384, 576, 768, 1000]))
         x = rng.standard_normal((M, K), dtype=np.float32); w = rng.standard_normal((N, K), dtype=np.float32) * K ** -0.5
         b = rng.standard_normal(N, dtype=np.float32) * 0.1 if rng.random() < 0.7 else None
         res = rng.standard_normal((M, N), dtype=np.float32) if rng.random() < 0.4 else None
