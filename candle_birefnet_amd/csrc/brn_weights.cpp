@@ -60,8 +60,8 @@ const brn_named_tensor* WeightTable::get(const std::string& name, std::initializ
     }
     if (!ok) {
         std::string want, got;
-        for (int64_t d : shape) want += std::to_string(d) + ",";
-        for (int i = 0; i < t->ndim; ++i) got += std::to_string(t->shape[i]) + ",";
+        for (int64_t d : shape) want += (want.empty() ? "" : ", ") + std::to_string(d);
+        for (int i = 0; i < t->ndim; ++i) got += (got.empty() ? "" : ", ") + std::to_string(t->shape[i]);
         fail(BRN_ERR_SHAPE, "shape mismatch for %s: expected [%s] got [%s]", name.c_str(), want.c_str(), got.c_str());
     }
     return t;
