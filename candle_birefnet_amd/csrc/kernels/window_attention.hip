@@ -577,9 +577,13 @@ __global__ void __launch_bounds__(ATT_BF16_HPW * ATT_THREADS) __attribute__((amd
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones8[e] = (__bf16)1.0f;
     // per key tile: koff = key0 + 11 (key0 / 12) for key0 = 16 kt + 4 g; the table word of (query, key0 + r) is rev[qrev + koff + r]
-    int koff[9];
+    // (byte offsets, one register per key tile, added to an LDS address the compiler cannot take apart: with `rev_s + qrev + koff[kt]`
+    // it re-associated the array's constant base out of the sum and spent four VALU instructions per key tile on addresses: 94 of the
+    // ~650 vector instructions of a query-tile triple)
+    typedef __attribute__((address_space(3))) const float lds_cfloat;
+    unsigned koffb[9];
 #pragma unroll
-    for (int kt = 0; kt < 9; ++kt) { const int key0 = kt * 16 + g * 4; koff[kt] = key0 + 11 * (key0 / WS); }
+    for (int kt = 0; kt < 9; ++kt) { const int key0 = kt * 16 + g * 4; koffb[kt] = (unsigned)(key0 + 11 * (key0 / WS)) * 4u; }
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
         const int qt = wv + 3 * u;
@@ -598,9 +602,11 @@ __global__ void __launch_bounds__(ATT_BF16_HPW * ATT_THREADS) __attribute__((amd
             if (kt % 3 == 2) __builtin_amdgcn_sched_barrier(0);
         }
         float mx = -3.0e38f;
+        unsigned tbq = (unsigned)(unsigned long)(lds_cfloat*)(rev_s + qrev);
+        asm volatile("" : "+v"(tbq));
 #pragma unroll
         for (int kt = 0; kt < 9; ++kt) {
-            const float* tb = rev_s + qrev + koff[kt];
+            lds_cfloat* tb = (lds_cfloat*)(unsigned long)(tbq + koffb[kt]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) st[kt][r] = fmaf(st[kt][r], scale2, tb[r]);
         }
