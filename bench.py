@@ -122,21 +122,41 @@ def launch_ranks(n, cmd, extra_env=None, timeout=None):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    import tempfile
+    import time
     procs = []
-    for r in range(n):
-        env = dict(os.environ)
-        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
-                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
-        if extra_env:
-            env.update(extra_env)
-        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate(timeout=timeout)
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        p.wait(timeout=timeout)
-        rc = rc or p.returncode
-    sys.stdout.write(out0.decode("utf-8", "replace"))
-    sys.stdout.flush()
+    with tempfile.TemporaryFile() as out0:
+        for r in range(n):
+            env = dict(os.environ)
+            env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                        "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+            if extra_env:
+                env.update(extra_env)
+            procs.append(subprocess.Popen(cmd, env=env, stdout=out0 if r == 0 else subprocess.DEVNULL))
+        # a rank that dies (no such device, out of memory ...) leaves the others waiting in the rendezvous or at a barrier: watch all
+        # of them, and when one fails stop the rest (exact PIDs, never a pattern) instead of hanging until somebody's timeout
+        t0, rc = time.time(), 0
+        while True:
+            codes = [p.poll() for p in procs]
+            failed = [c for c in codes if c not in (None, 0)]
+            if failed or all(c is not None for c in codes) or (timeout and time.time() - t0 > timeout):
+                if not failed and any(c is None for c in codes):
+                    failed = [124]                                   # timed out
+                rc = failed[0] if failed else 0
+                break
+            time.sleep(0.2)
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        out0.seek(0)
+        sys.stdout.write(out0.read().decode("utf-8", "replace"))
+        sys.stdout.flush()
     return rc
 
 

@@ -30,6 +30,18 @@ def test_launch_ranks_propagates_failure(capfd):
     capfd.readouterr()
 
 
+def test_launch_ranks_stops_the_others_when_one_rank_dies(capfd):
+    """rank 1 exits with an error at once, rank 0 would wait for it forever (the rendezvous of a real run): the launcher must stop rank 0
+    and return the failure within seconds instead of hanging"""
+    import time
+    import bench
+    code = "import os, sys, time\nif os.environ['RANK'] == '1': sys.exit(7)\ntime.sleep(600)\n"
+    t0 = time.time()
+    rc = bench.launch_ranks(2, [sys.executable, "-c", code])
+    assert rc == 7 and time.time() - t0 < 60
+    capfd.readouterr()
+
+
 def test_bench_refuses_world_size_mismatch():
     """`--gpus 8` under WORLD_SIZE=2 (or --gpus 1 under WORLD_SIZE=2) must fail before any GPU work, not print n_gpus: 1"""
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
