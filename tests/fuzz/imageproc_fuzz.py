@@ -1,7 +1,7 @@
 """random image sizes / channel counts / model sizes through brn_preprocess_image and brn_postprocess_mask against the numpy restatement
-of the image crate's resampler (oracle/image_oracle.py): pre-processing bit-exact, masks within one grey level.  tools/imageproc_fuzz.py [n] [seed]"""
+of the image crate's resampler (oracle/image_oracle.py): pre-processing bit-exact, masks within one grey level.  tests/fuzz/imageproc_fuzz.py [n] [seed]   (lives under tests/: it checks against oracle/, which only tests may use)"""
 import sys, os, numpy as np
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root)
 from oracle import image_oracle as O
 from candle_birefnet_amd.imageproc import preprocess_image, postprocess_mask

@@ -74,9 +74,9 @@ def test_end_to_end_png_to_mask(gpu, tmp_path):
 
 
 def test_imageproc_size_fuzz(gpu):
-    """tools/imageproc_fuzz.py: 40 random (image size, channel count, model size, output size) combinations, 1 x 1 up to 700 x 700,
+    """tests/fuzz/imageproc_fuzz.py: 40 random (image size, channel count, model size, output size) combinations, 1 x 1 up to 700 x 700,
     through both entry points against the resampler restatement: pre-processing bit-exact, masks within one grey level."""
     import subprocess
-    pr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "imageproc_fuzz.py"), "40", "7"], capture_output=True, text=True, timeout=900)
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "imageproc_fuzz.py"), "40", "7"], capture_output=True, text=True, timeout=900)
     assert pr.returncode == 0, pr.stderr[-2000:]
     assert "40 cases, 0 problems" in pr.stdout, pr.stdout[-3000:]
