@@ -6,6 +6,6 @@ loudly if it is missing: there is no CPU path in the product."""
 from ._ffi import BrnError, LIB_PATH, device_count  # noqa: F401  (loads the shared library)
 from .config import BiRefNetConfig, DecoderConfig, SwinConfig  # noqa: F401
 from .weights import VarBuilder, birefnet_weight_spec, swin_weight_spec, synth_input, synth_weights  # noqa: F401
-from .birefnet import BiRefNet, DeformableConv2d, SwinTransformer  # noqa: F401
+from .birefnet import BiRefNet, BiRefNetDecoder, DeformableConv2d, SqueezeModule, SwinTransformer  # noqa: F401
 from . import ops  # noqa: F401
 from . import imageproc  # noqa: F401

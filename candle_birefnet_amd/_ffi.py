@@ -76,6 +76,7 @@ _sig("brn_model_create", C.c_int, C.POINTER(brn_config), C.POINTER(brn_named_ten
      C.c_int, C.c_int, C.c_int, C.POINTER(_vp))
 _sig("brn_model_create_from_safetensors", C.c_int, C.POINTER(brn_config), C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
      C.c_int, C.c_int, C.POINTER(_vp))
+_sig("brn_decoder_create", C.c_int, C.POINTER(brn_config), C.POINTER(brn_named_tensor), C.c_size_t, C.c_char_p, C.c_int, C.c_int, C.POINTER(_vp))
 _sig("brn_model_destroy", None, _vp)
 _sig("brn_forward_logits", C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp)
 _sig("brn_forward", C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp)
@@ -104,6 +105,9 @@ _sig("brn_deform_conv2d_forward", C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_i
 
 _sig("brn_aspp_deformable_forward", C.c_int, _vp, C.c_size_t, C.c_char_p, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp)
 
+_sig("brn_decblk_forward", C.c_int, _vp, C.c_size_t, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int,
+     C.c_int, _vp)
+
 _sig("brn_preprocess_image", C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp)
 _sig("brn_postprocess_mask", C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp)
 _sig("brn_set_op_compute", C.c_int, C.c_int)
@@ -113,12 +117,12 @@ if hasattr(lib, "brn_gemm_microbench"):   # only in libbirefnet_hip_diag.so (mak
 # every symbol include/birefnet_hip.h declares (checked by tests/test_abi.py against the header text)
 DECLARED = [
     "brn_abi_version", "brn_last_error", "brn_build_info", "brn_device_count", "brn_config_default_swin_l",
-    "brn_config_lateral_channels", "brn_config_x4_channels", "brn_model_create", "brn_model_create_from_safetensors", "brn_model_destroy", "brn_forward_logits",
+    "brn_config_lateral_channels", "brn_config_x4_channels", "brn_model_create", "brn_model_create_from_safetensors", "brn_decoder_create", "brn_model_destroy", "brn_forward_logits",
     "brn_forward", "brn_model_backbone_forward", "brn_model_squeeze_forward", "brn_model_decoder_forward",
     "brn_model_set_profiling", "brn_model_last_timings", "brn_model_last_kernel_stats", "brn_kernel_family_name",
     "brn_swin_create", "brn_swin_destroy", "brn_swin_forward", "brn_linear_forward", "brn_layer_norm_forward",
     "brn_conv2d_forward", "brn_upsample_bilinear2d", "brn_window_attention_forward", "brn_patch_merging_forward",
-    "brn_deform_conv2d_forward", "brn_aspp_deformable_forward", "brn_set_op_compute", "brn_preprocess_image", "brn_postprocess_mask",
+    "brn_deform_conv2d_forward", "brn_aspp_deformable_forward", "brn_decblk_forward", "brn_set_op_compute", "brn_preprocess_image", "brn_postprocess_mask",
 ]
 
 

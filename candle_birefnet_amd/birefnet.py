@@ -153,6 +153,57 @@ class BiRefNet:
                 for i in range(no.value)}
 
 
+class BiRefNetDecoder:
+    """birefnet.rs:121-377 on its own: BiRefNetDecoder::new(config, vb) / forward(x, x1, x2, x3, x4) — a handle that holds only the
+    decoder's weights (brn_decoder_create); `vb` is positioned at the decoder's prefix (vb.pp("decoder") in birefnet.rs:401)."""
+
+    def __init__(self, config: BiRefNetConfig, vb, device: int = 0, compute: str = "f32"):
+        self.config = config
+        self._h = C.c_void_p()
+        cfg = config.to_c()
+        arr, keep = _named_array(vb.tensors_under_prefix())
+        _ffi.check(_ffi.lib.brn_decoder_create(C.byref(cfg), arr, len(arr), b"", device, BiRefNet.COMPUTE[compute], C.byref(self._h)))
+        del keep
+
+    @staticmethod
+    def new(config, vb, **kw):
+        return BiRefNetDecoder(config, vb, **kw)
+
+    forward = BiRefNet._decoder_forward
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            _ffi.lib.brn_model_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SqueezeModule:
+    """birefnet.rs:70-94 on its own: SqueezeModule::new(in_channels, out_channels, vb) = one BasicDecBlk under vb.pp("0"), with the
+    ASPP always on (birefnet.rs:76-79)."""
+
+    def __init__(self, in_channels, out_channels, vb, mode="reference_cpu", device=0):
+        self.in_channels, self.out_channels, self.mode, self.device = in_channels, out_channels, mode, device
+        self._t = vb.pp("0").tensors_under_prefix()
+
+    @staticmethod
+    def new(*a, **kw):
+        return SqueezeModule(*a, **kw)
+
+    def forward(self, x):
+        from . import ops
+        if int(x.shape[1]) != self.in_channels:
+            raise ValueError(f"expected {self.in_channels} input channels, got {int(x.shape[1])}")
+        return ops.decblk(x, self._t, self.out_channels, mode=self.mode, device=self.device)
+
+    __call__ = forward
+
+
 def _stage_dims(H, W, patch):
     h, w = -(-H // patch), -(-W // patch)
     hs, ws = [], []

@@ -166,10 +166,42 @@ static void validate_config(const brn_config& c) {
 
 static void run_model_locked(Model* m, const float* x, int B, int H, int W, brn_mem in_loc, float* out, brn_mem out_loc, void* stream, int apply_sigmoid);
 
+// sub-batches a device-resident batch of B images runs as (BRN_SPLIT_STREAMS, default 2; at least two images per part)
+static int sub_batch_parts(int B) {
+    static const int parts_env = getenv("BRN_SPLIT_STREAMS") ? atoi(getenv("BRN_SPLIT_STREAMS")) : 2;
+    int parts = parts_env < 1 ? 1 : (parts_env > 8 ? 8 : parts_env);
+    if (parts > B / 2) parts = B / 2;
+    return parts < 1 ? 1 : parts;
+}
+// streams, events and workspaces of parts 1 .. parts-1, each workspace as large as the main one (which plan_model sized for the
+// largest part).  false = a workspace could not be allocated (the caller then runs the batch as one part); nothing is left half-made
+static bool ensure_side_arenas(Model& m, int parts) {
+    if ((int)m.sides.size() < parts - 1) m.sides.resize(parts - 1);
+    for (int k = 0; k < parts - 1; ++k) {
+        Model::Side& sd = m.sides[k];
+        if (!sd.stream) {
+            BRN_HIP(hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking));
+            BRN_HIP(hipEventCreateWithFlags(&sd.join_ev, hipEventDisableTiming));
+        }
+        if (sd.arena.base && sd.arena.cap >= m.arena.cap) continue;
+        if (sd.arena.base) { BRN_HIP(hipDeviceSynchronize()); (void)hipFree(sd.arena.base); sd.arena.base = nullptr; sd.arena.cap = 0; }
+        void* d = nullptr;
+        const char* fault = getenv("BRN_FAULT_SIDE_ARENA");       // test hook: behave as if this allocation had failed
+        hipError_t e = (fault && atoi(fault) != 0) ? hipErrorOutOfMemory : hipMalloc(&d, m.arena.cap);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();                               // (must not be reported by the next launch check)
+            return false;
+        }
+        sd.arena.base = (char*)d; sd.arena.cap = m.arena.cap;
+    }
+    return true;
+}
+
 static void run_model(Model* m, const float* x, int B, int H, int W, brn_mem in_loc, float* out, brn_mem out_loc, void* stream,
                       int apply_sigmoid) {
     if (!m || !x || !out) fail(BRN_ERR_INVALID_ARG, "null argument");
     if (B < 1) fail(BRN_ERR_INVALID_ARG, "batch must be >= 1");
+    if (m->decoder_only) fail(BRN_ERR_INVALID_ARG, "this handle holds only the decoder (brn_decoder_create): forward_logits needs a whole model");
     std::lock_guard<std::mutex> lk(m->mu);
     try {
         run_model_locked(m, x, B, H, W, in_loc, out, out_loc, stream, apply_sigmoid);
@@ -185,7 +217,17 @@ static void run_model_locked(Model* m, const float* x, int B, int H, int W, brn_
                              int apply_sigmoid) {
     BRN_HIP(hipSetDevice(m->device));
     hipStream_t s = (hipStream_t)stream;
-    plan_model(*m, B, H, W);
+    // a device-resident batch runs as `parts` sub-batches, each on its own stream with its own workspace (below): what has to fit a
+    // workspace is then the LARGEST PART, and that is the shape the dry run plans (its GEMM plans — tiles, split-K scratch — are those of
+    // the part, not of the whole batch); every workspace, the main one included, is sized to that peak
+    int parts = sub_batch_parts(B);
+    bool split = parts > 1 && !m->profiling && in_loc == BRN_MEM_DEVICE && out_loc == BRN_MEM_DEVICE;
+    plan_model(*m, split ? (B + parts - 1) / parts : B, H, W);
+    if (split && !ensure_side_arenas(*m, parts)) {
+        // no memory for a second workspace: the batch runs as one part on one stream (planned as such) instead of failing
+        split = false; parts = 1;
+        plan_model(*m, B, H, W);
+    }
     if (!m->done_ev) BRN_HIP(hipEventCreateWithFlags(&m->done_ev, hipEventDisableTiming));
     if (m->has_last && m->last_stream != s) BRN_HIP(hipStreamWaitEvent(s, m->done_ev, 0));   // previous forward still owns the arena
     m->arena.top = 0;
@@ -227,43 +269,47 @@ static void run_model_locked(Model* m, const float* x, int B, int H, int W, brn_
         }
         return &bs;
     };
-    static const int parts_env = getenv("BRN_SPLIT_STREAMS") ? atoi(getenv("BRN_SPLIT_STREAMS")) : 2;
-    int parts = parts_env < 1 ? 1 : (parts_env > 8 ? 8 : parts_env);
-    if (parts > B / 2) parts = B / 2;                              // at least two images per part
-    if (parts > 1 && !m->profiling && in_loc == BRN_MEM_DEVICE && out_loc == BRN_MEM_DEVICE) {
+    if (split) {
         if (branches_env < 0) branches_on = false;
         if (!m->fork_ev) BRN_HIP(hipEventCreateWithFlags(&m->fork_ev, hipEventDisableTiming));
-        if ((int)m->sides.size() < parts - 1) m->sides.resize(parts - 1);
         for (int k = 0; k < parts - 1; ++k) {
             Model::Side& sd = m->sides[k];
-            if (!sd.stream) {
-                BRN_HIP(hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking));
-                BRN_HIP(hipEventCreateWithFlags(&sd.join_ev, hipEventDisableTiming));
-            }
-            if (!sd.arena.base || sd.arena.cap < m->arena.cap) {
-                if (sd.arena.base) { BRN_HIP(hipDeviceSynchronize()); (void)hipFree(sd.arena.base); sd.arena.base = nullptr; }
-                void* d = nullptr;
-                hipError_t e = hipMalloc(&d, m->arena.cap);
-                if (e != hipSuccess) fail(BRN_ERR_OOM, "workspace hipMalloc of %zu bytes for stream %d failed: %s", m->arena.cap, k + 1, hipGetErrorString(e));
-                sd.arena.base = (char*)d; sd.arena.cap = m->arena.cap;
-            }
             sd.arena.top = 0; sd.arena.peak = 0; sd.arena.dry = false;
         }
+        // BRN_CU_PARTITION (A/B switch, two parts only): each part's stream is confined to its own half of the chip by a CU mask
+        // (hipExtStreamCreateWithCUMask; mask bit i = CU i / 8 of XCD i % 8): 1 = half the CUs of every XCD (both parts share every L2),
+        // 2 = four whole XCDs each.  The persistent GEMM grids are sized for the CUs of the mask (set_launch_cus).
+        static const int cu_part = getenv("BRN_CU_PARTITION") ? atoi(getenv("BRN_CU_PARTITION")) : 0;
+        const bool masked = cu_part > 0 && parts == 2;
+        if (masked && !m->cu_stream[0]) {
+            for (int k = 0; k < 2; ++k) {
+                uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int i = 0; i < 256; ++i) {
+                    const bool mine = cu_part == 2 ? ((i % 8 < 4) == (k == 0)) : ((i < 128) == (k == 0));
+                    if (mine) mask[i >> 5] |= 1u << (i & 31);
+                }
+                BRN_HIP(hipExtStreamCreateWithCUMask(&m->cu_stream[k], 8, mask));
+                BRN_HIP(hipEventCreateWithFlags(&m->cu_join_ev[k], hipEventDisableTiming));
+            }
+        }
+        struct CusGuard { bool on; explicit CusGuard(bool o) : on(o) { if (on) set_launch_cus(128); } ~CusGuard() { if (on) set_launch_cus(256); } } cus_guard(masked);
         BRN_HIP(hipEventRecord(m->fork_ev, s));
         int b0 = 0;
         for (int k = 0; k < parts; ++k) {
             const int bk = B / parts + (k < B % parts ? 1 : 0);
-            hipStream_t sk = k == 0 ? s : m->sides[k - 1].stream;
-            if (k > 0) BRN_HIP(hipStreamWaitEvent(sk, m->fork_ev, 0));
+            hipStream_t sk = masked ? m->cu_stream[k] : (k == 0 ? s : m->sides[k - 1].stream);
+            if (k > 0 || masked) BRN_HIP(hipStreamWaitEvent(sk, m->fork_ev, 0));
             Ctx ck{k == 0 ? &m->arena : &m->sides[k - 1].arena, sk, false, false, nullptr, nullptr, nullptr};
             ck.bf16 = m->bf16;
             ck.br = branch_set(k);
             if (branches_env > 0) ck.br_mask = (unsigned)branches_env;
             model_forward(*m, ck, dx + (size_t)b0 * 3 * H * W, bk, H, W, dout + (size_t)b0 * H * W, apply_sigmoid);
-            if (k > 0) BRN_HIP(hipEventRecord(m->sides[k - 1].join_ev, sk));
+            if (masked) BRN_HIP(hipEventRecord(m->cu_join_ev[k], sk));
+            else if (k > 0) BRN_HIP(hipEventRecord(m->sides[k - 1].join_ev, sk));
             b0 += bk;
         }
-        for (int k = 1; k < parts; ++k) BRN_HIP(hipStreamWaitEvent(s, m->sides[k - 1].join_ev, 0));
+        if (masked) { for (int k = 0; k < 2; ++k) BRN_HIP(hipStreamWaitEvent(s, m->cu_join_ev[k], 0)); }
+        else for (int k = 1; k < parts; ++k) BRN_HIP(hipStreamWaitEvent(s, m->sides[k - 1].join_ev, 0));
         BRN_HIP(hipEventRecord(m->done_ev, s));
         m->last_stream = s; m->has_last = true;
         return;
@@ -296,7 +342,7 @@ const char* brn_last_error(void) { return last_error_cstr(); }
 const char* brn_build_info(void) {
 #define BRN_STR2(x) #x
 #define BRN_STR(x) BRN_STR2(x)
-    return "libbirefnet_hip gfx950 (CDNA4) fp32 MFMA path; HIP " BRN_STR(HIP_VERSION_MAJOR) "." BRN_STR(HIP_VERSION_MINOR) "." BRN_STR(HIP_VERSION_PATCH);
+    return "libbirefnet_hip gfx950 (CDNA4): compute modes f32 (fp32 MFMA), f32_split3 / f32_split2 (split-bf16 MFMA, fp32 storage), bf16 (bf16 storage + MFMA); HIP " BRN_STR(HIP_VERSION_MAJOR) "." BRN_STR(HIP_VERSION_MINOR) "." BRN_STR(HIP_VERSION_PATCH);
 }
 brn_status brn_device_count(int* n) {
     return guarded([&] {
@@ -361,7 +407,32 @@ brn_status brn_model_create(const brn_config* cfg, const brn_named_tensor* weigh
         build_decblk_weights(wt, "squeeze_module.0.", brn_config_x4_channels(cfg), lat[3], cfg->deform_mode, m.own, m.squeeze);   // birefnet.rs:397-399
         build_decoder_weights(wt, "decoder.", *cfg, m.own, m.dec);                        // birefnet.rs:401
         m.has_decoder = true;
-        if (max_batch > 0 && max_h > 0 && max_w > 0) plan_model(m, max_batch, max_h, max_w);
+        // (the batch the caller announces will run as sub_batch_parts(max_batch) parts when it is device-resident: plan the part;
+        // a host-resident or profiled call of that batch re-plans for the whole batch when it comes)
+        if (max_batch > 0 && max_h > 0 && max_w > 0) { const int pp = sub_batch_parts(max_batch); plan_model(m, (max_batch + pp - 1) / pp, max_h, max_w); }
+        *out = h.release();
+    });
+}
+brn_status brn_decoder_create(const brn_config* cfg, const brn_named_tensor* weights, size_t n, const char* prefix, int device, brn_dtype dt,
+                              brn_model** out) {
+    return guarded([&] {
+        if (!cfg || !weights || !out) fail(BRN_ERR_INVALID_ARG, "null argument");
+        int planes = 0;
+        if (dt == BRN_F32) planes = 0;
+        else if (dt == BRN_F32_SPLIT3) planes = 3;
+        else if (dt == BRN_F32_SPLIT2) planes = 2;
+        else if (dt == BRN_BF16) planes = BUILD_BF16;
+        else fail(BRN_ERR_INVALID_ARG, "unsupported compute dtype %d", (int)dt);
+        struct PlanesGuard { PlanesGuard(int p) { set_build_planes(p); } ~PlanesGuard() { set_build_planes(0); } } guard(planes);
+        *out = nullptr;
+        ensure_device(device);
+        validate_config(*cfg);
+        std::unique_ptr<brn_model> h(new brn_model());
+        Model& m = h->m;
+        m.cfg = *cfg; m.device = device; m.bf16 = dt == BRN_BF16;
+        WeightTable wt(weights, n);
+        build_decoder_weights(wt, prefix ? prefix : "", *cfg, m.own, m.dec);               // birefnet.rs:170-273
+        m.has_decoder = true; m.decoder_only = true;
         *out = h.release();
     });
 }
@@ -457,6 +528,7 @@ brn_status brn_model_backbone_forward(brn_model* m, const float* x, int B, int H
                                       brn_mem out_loc, void* stream) {
     return guarded([&] {
         if (!m) fail(BRN_ERR_INVALID_ARG, "null model");
+        if (m->m.decoder_only) fail(BRN_ERR_INVALID_ARG, "this handle holds only the decoder (brn_decoder_create)");
         std::lock_guard<std::mutex> lk(m->m.mu);
         swin_entry(m->m.swin, m->m.device, x, B, H, W, in_loc, outs, out_loc, stream, m->m.bf16);
     });
@@ -466,6 +538,7 @@ brn_status brn_model_squeeze_forward(brn_model* m, const float* x4, int B, int h
                                      brn_mem out_loc, void* stream) {
     return guarded([&] {
         if (!m || !x4 || !out) fail(BRN_ERR_INVALID_ARG, "null argument");
+        if (m->m.decoder_only) fail(BRN_ERR_INVALID_ARG, "this handle holds only the decoder (brn_decoder_create)");
         std::lock_guard<std::mutex> lk(m->m.mu);
         BRN_HIP(hipSetDevice(m->m.device));
         const int cin = m->m.squeeze.cin, cout = m->m.squeeze.cout;
@@ -861,6 +934,35 @@ brn_status brn_aspp_deformable_forward(const brn_named_tensor* weights, size_t n
             aspp_forward(c, a, T, U, mode);
             if (!c.dry) BRN_HIP(launch_nhwc_to_nchw(U.p, B, 64, H, W, U.ld, 0, dy, c.stream, c.bf16));
         }, g_op_planes == BUILD_BF16);
+        st.finish();
+    });
+}
+
+brn_status brn_decblk_forward(const brn_named_tensor* weights, size_t n, const char* prefix, int cin, int cout, int use_aspp, int mode,
+                              const float* x, int B, int H, int W, float* y, brn_mem loc, int device, void* stream) {
+    return guarded([&] {
+        if (!weights || !x || !y || B < 1 || H < 1 || W < 1 || cin < 1 || cout < 1) fail(BRN_ERR_INVALID_ARG, "bad argument");
+        if (mode != BRN_DEFORM_REFERENCE_CPU && mode != BRN_DEFORM_DEFORMABLE) fail(BRN_ERR_INVALID_ARG, "unknown deform mode %d", mode);
+        ensure_device(device);
+        DeviceOwner own;
+        OpPlanes op_planes;
+        WeightTable wt(weights, n);
+        DecBlkW blk;
+        build_decblk_weights(wt, prefix ? prefix : "", cin, cout, mode, own, blk, use_aspp != 0);
+        const int cinp = blk.conv_in.Cinp;                   // in_channels rounded up to the kernels' channel granule (zero weights there)
+        const bool bf = g_op_planes == BUILD_BF16;
+        Staging st(stream, loc);
+        const float* dx = st.in(x, (size_t)B * cin * H * W);
+        float* dy = st.out(y, (size_t)B * cout * H * W);
+        with_arena((hipStream_t)stream, [&](Ctx& c) {
+            Map X = new_map(c, B, H, W, cinp), Y = new_map(c, B, H, W, cout);
+            if (!c.dry) {
+                if (cinp != cin) BRN_HIP(hipMemsetAsync(X.p, 0, (size_t)B * H * W * cinp * c.esz(), c.stream));   // the pad channels
+                BRN_HIP(launch_nchw_to_nhwc(dx, B, cin, H, W, X.p, X.ld, 0, c.stream, c.bf16));
+            }
+            decblk_forward(c, blk, X, Y, mode);
+            if (!c.dry) BRN_HIP(launch_nhwc_to_nchw(Y.p, B, cout, H, W, Y.ld, 0, dy, c.stream, c.bf16));
+        }, bf);
         st.finish();
     });
 }

@@ -503,6 +503,11 @@ void decblk_forward(Ctx& c, const DecBlkW& w, const Map& in, const Map& out, int
     const size_t mk = c.arena->mark();
     Map t = new_map(c, in.B, in.H, in.W, 64);
     run_conv(c, w.conv_in, in, t);                                   // conv_in + bn_in + relu
+    if (!w.has_aspp) {                                               // dec_att is None (decoder.rs:131-135)
+        run_conv(c, w.conv_out, t, out);
+        c.arena->release(mk);
+        return;
+    }
     Map u = new_map(c, in.B, in.H, in.W, 64);
     aspp_forward(c, w.aspp, t, u, deform_mode);
     run_conv(c, w.conv_out, u, out);                                 // conv_out + bn_out (no ReLU)
@@ -739,6 +744,10 @@ Model::~Model() {
         if (sd.join_ev) (void)hipEventDestroy(sd.join_ev);
     }
     if (fork_ev) (void)hipEventDestroy(fork_ev);
+    for (int k = 0; k < 2; ++k) {
+        if (cu_stream[k]) (void)hipStreamDestroy(cu_stream[k]);
+        if (cu_join_ev[k]) (void)hipEventDestroy(cu_join_ev[k]);
+    }
     for (BranchSet& bs : branch_sets)
         for (int i = 0; i < BRN_AUX_STREAMS; ++i) {
             if (bs.stream[i]) (void)hipStreamDestroy(bs.stream[i]);

@@ -141,7 +141,7 @@ struct ASPPW {             // ASPPDeformable (aspp.rs:227-333)
     float* conv1_full = nullptr;   // [64][1280] (for the pooled branch's contribution)
     GemmW conv1_main;      // [64][1024] + bn1 + relu
 };
-struct DecBlkW { GemmW conv_in; ASPPW aspp; GemmW conv_out; int cin = 0, cout = 0; };
+struct DecBlkW { GemmW conv_in; ASPPW aspp; GemmW conv_out; int cin = 0, cout = 0; bool has_aspp = true; /* dec_att is Some (decoder.rs:107-111) */ };
 struct SimpleConvsW { GemmW conv1, conv_out; };
 struct DecoderW {
     SimpleConvsW ipt[5];   // ipt_blk2..5 at [1..4]; ipt_blk1 ([0]) is composed into head_k / head_b
@@ -189,6 +189,7 @@ struct Model {
     DecBlkW squeeze;
     DecoderW dec;
     bool has_decoder = false;
+    bool decoder_only = false;                // brn_decoder_create: no backbone / squeeze weights behind this handle
     Arena arena;
     int plan_B = 0, plan_H = 0, plan_W = 0;   // the largest request planned last (a request <= it in every dimension fits)
     struct Planned { int B, H, W; };
@@ -200,6 +201,7 @@ struct Model {
     // two half batches on two streams (run_model): second workspace, side stream, fork / join events
     struct Side { Arena arena; hipStream_t stream = nullptr; hipEvent_t join_ev = nullptr; };
     std::vector<Side> sides; hipEvent_t fork_ev = nullptr;
+    hipStream_t cu_stream[2] = {nullptr, nullptr}; hipEvent_t cu_join_ev[2] = {nullptr, nullptr};   // BRN_CU_PARTITION: CU-masked streams of the two parts
     std::vector<BranchSet> branch_sets;   // one per sub-batch stream (run_model)
     bool profiling = false;
     bool bf16 = false;        // BRN_BF16: bf16 activations / weights in HBM
@@ -213,7 +215,8 @@ struct Model {
 
 void build_swin_weights(const WeightTable& wt, const std::string& prefix, const brn_config& cfg, DeviceOwner& own, SwinW& out);
 void build_aspp_weights(const WeightTable& wt, const std::string& prefix, int deform_mode, DeviceOwner& own, ASPPW& out);
-void build_decblk_weights(const WeightTable& wt, const std::string& prefix, int cin, int cout, int deform_mode, DeviceOwner& own, DecBlkW& out);
+void build_decblk_weights(const WeightTable& wt, const std::string& prefix, int cin, int cout, int deform_mode, DeviceOwner& own, DecBlkW& out,
+                          bool use_aspp = true);
 void build_decoder_weights(const WeightTable& wt, const std::string& prefix, const brn_config& cfg, DeviceOwner& own, DecoderW& out);
 
 // generic weight repack helpers (also used by the op-level entry points)

@@ -57,6 +57,9 @@ GemmPlan plan_gemm(int M, int N, int K, int planes = 0);   // planes: bf16 plane
 // ws: plan.ws_floats floats of scratch when plan.splitk > 1.  Returns the hipError_t of the launch(es).
 hipError_t launch_gemm(const GemmParams& p, const GemmPlan& plan, float* ws, hipStream_t s);
 
+// CUs the persistent grids (gemm_bf16_kernel, gemm_wstat_*) are sized for on the calling host thread: 256 unless the launch stream carries a CU mask
+int launch_cus();
+void set_launch_cus(int n);
 // bf16-storage mode: plan + launch (kernels/gemm_bf16.hip).  cfg: 0 = 128x128, 1 = 128x64, 2 = 256x256, 3 = 256x192 block tile
 GemmPlan plan_gemm_bf16(int M, int N, int K, bool f32_residual = false, bool gelu = false);   // f32_residual: fp32 C with an fp32 residual (proj / fc2)
 hipError_t launch_gemm_bf16(const GemmParams& p, const GemmPlan& plan, float* ws, hipStream_t s);

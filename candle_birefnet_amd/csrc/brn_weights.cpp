@@ -328,16 +328,16 @@ static GemmW conv_bn(const WeightTable& wt, const std::string& conv, bool has_bi
 }
 
 void build_decblk_weights(const WeightTable& wt, const std::string& p, int cin, int cout, int deform_mode, DeviceOwner& own,
-                          DecBlkW& out) {
+                          DecBlkW& out, bool use_aspp) {
     const int IC = 64;             // inter_channels (decoder.rs:96)
-    out.cin = cin; out.cout = cout;
-    if (cin % 32) fail(BRN_ERR_INVALID_ARG, "decoder block in_channels %d must be a multiple of 32", cin);
-    // (bf16-storage mode: an input channel count that is not a multiple of 64 — decoder_block1's 480 — is padded with zero weights to the
-    // next multiple, so that the conv runs chunk-major; the caller's map then carries that many channels, the pad ones zero)
-    const int cin_pad = (g_build_planes == BUILD_BF16 && cin % 64) ? roundup(cin, 64) : cin;
+    out.cin = cin; out.cout = cout; out.has_aspp = use_aspp;
+    // The channels-last convs read whole 32-channel granules (64 in the bf16-storage mode, where e.g. decoder_block1's 480 is padded so
+    // that the conv runs chunk-major): an input channel count off the granule is padded with zero weights to the next multiple; the
+    // caller's map then carries conv_in.Cinp channels, the pad ones zero.  (Every block of the model has in_channels % 32 == 0.)
+    const int cin_pad = roundup(cin, g_build_planes == BUILD_BF16 ? 64 : 32);
     out.conv_in = conv_bn(wt, p + "conv_in", true, p + "bn_in", IC, cin, cin_pad, 3, 1, ACT_RELU, own);
     out.conv_out = conv_bn(wt, p + "conv_out", true, p + "bn_out", cout, IC, IC, 3, 1, ACT_NONE, own);   // no ReLU (decoder.rs:138-139)
-    build_aspp_weights(wt, p + "dec_att.", deform_mode, own, out.aspp);
+    if (use_aspp) build_aspp_weights(wt, p + "dec_att.", deform_mode, own, out.aspp);                     // decoder.rs:107-111
 }
 
 // ASPPDeformable::new (aspp.rs:236-300) for in_channels = 64 under prefix `ap`

@@ -695,6 +695,13 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
 // The C tile goes back through the A buffer it came from (two 32-row halves, 512-byte rows, XOR-ed chunks) and leaves as 384-byte
 // row segments.
 // =====================================================================================================================
+constexpr int WSTAT_WG_PER_CU = 2;      // 2: <= 256 VGPRs, no spill (forced to 168 for three per CU the kernel spills 30-40 registers)
+// CUs the persistent grids of this file are sized for: 256, or the size of the CU mask of the stream being launched on (a sub-batch
+// stream confined to a part of the chip, brn_api.cpp run_model); thread-local: set by the host thread that enqueues the forward
+static thread_local int g_launch_cus = 256;
+int launch_cus() { return g_launch_cus; }
+void set_launch_cus(int n) { g_launch_cus = n < 8 ? 8 : (n > 256 ? 256 : n) / 8 * 8; }
+
 __device__ __forceinline__ int ws_slot(int r, int c) { return (r >> 1) * 256 + (((((r & 1) << 3) | c) ^ ((r >> 1) & 15)) << 4); }
 
 // WBM = rows per A tile: 64 at K = 192 (two 24-KB buffers), 32 at K = 384 (the W slice is 144 VGPRs there; two 24-KB buffers again,
@@ -961,20 +968,23 @@ bool gemm_wstat_ln_eligible(const GemmParams& p) {
 }
 hipError_t launch_gemm_wstat_ln(const GemmParams& p, const float* gamma, const float* beta, float eps, void* y_bf16, int ldy, hipStream_t s) {
     if (!gemm_wstat_ln_eligible(p) || !gamma || !beta || !y_bf16 || (ldy & 3)) return hipErrorInvalidValue;
-    dim3 grid(8 * (256 * 2 / 8)), block(256);
+    dim3 grid(8 * (launch_cus() * 2 / 8)), block(256);
     hipLaunchKernelGGL(gemm_wstat_ln_bf16_kernel, grid, block, 0, s, p, gamma, beta, eps, reinterpret_cast<__bf16*>(y_bf16), ldy);
     return hipGetLastError();
 }
 
-constexpr int WSTAT_WG_PER_CU = 2;      // 2: <= 256 VGPRs, no spill (forced to 168 for three per CU the kernel spills 30-40 registers)
 bool gemm_wstat_eligible(const GemmParams& p) {
-    return p.mode == GEMM_DENSE && p.Wp && (p.K == 192 || p.K == 384) && p.N >= 192 && (p.N % 192) == 0 && !p.c_f32 && !p.R && !p.scale && !p.bbias &&
+    // (N / 192 column groups share the chip's workgroup slots: beyond that many groups there is no walker left per group, and the
+    // tiled kernel serves the shape)
+    return p.mode == GEMM_DENSE && p.Wp && (p.K == 192 || p.K == 384) && p.N >= 192 && (p.N % 192) == 0 && p.N / 192 <= launch_cus() * WSTAT_WG_PER_CU / 8 &&
+           !p.c_f32 && !p.R && !p.scale && !p.bbias &&
            ((p.lda | p.a_coff | p.ldc | p.c_coff) & 7) == 0 && p.M >= 32768 && (long)p.lda * 2 * 64 < 0x7fffffffL;
 }
 hipError_t launch_gemm_wstat(const GemmParams& p, hipStream_t s) {
     if (!gemm_wstat_eligible(p)) return hipErrorInvalidValue;
     const int G = p.N / 192;
-    const int nw = (256 * WSTAT_WG_PER_CU / 8) / G;
+    const int nw = (launch_cus() * WSTAT_WG_PER_CU / 8) / G;
+    if (nw < 1) return hipErrorInvalidValue;
     dim3 grid(8 * G * nw), block(256);
     if (p.K == 384) {
         if (p.act == ACT_GELU_ERF) hipLaunchKernelGGL((gemm_wstat_bf16_kernel<6, ACT_GELU_ERF, 32>), grid, block, 0, s, p);
@@ -1013,7 +1023,7 @@ static hipError_t launch_bf16_cfg(const GemmParams& p, hipStream_t s) {
     // persistent workgroups: as many as fit the chip at once (LDS-limited: NSTAGE ring slots each), never more than work items
     constexpr int LDS_BYTES = NSTAGE * (BM + BN) * BBK * 2;
     constexpr int WG_PER_CU = (160 * 1024 / LDS_BYTES) < (2048 / (WM * WN * 64)) ? (160 * 1024 / LDS_BYTES) : (2048 / (WM * WN * 64));
-    const int slots = 256 * (WG_PER_CU < 1 ? 1 : WG_PER_CU);
+    const int slots = launch_cus() * (WG_PER_CU < 1 ? 1 : WG_PER_CU);
     dim3 grid(tiles < slots ? tiles : slots), block(WM * WN * 64);
     // epilogue flavour (see the kernel): 0 = bf16 out, 1 = fp32 out (+ fp32 residual), 2 = generic
     int epi = 2;

@@ -613,9 +613,11 @@ __global__ void __launch_bounds__(ATT_BF16_HPW * ATT_THREADS) __attribute__((amd
         if (has_mask) {
 #pragma unroll
             for (int kt = 0; kt < 9; ++kt) {
-                // byte r of x is non-zero where key r lies in another region than the query: one byte-to-float conversion and one fma per
-                // score.  A region distance d > 1 adds -100 d instead of -100: both are weights below 1e-43 (swin.rs:283-296 adds -100)
-                const unsigned x = *reinterpret_cast<const unsigned*>(rid_s + kt * 16 + g * 4) ^ qrid4;
+                // byte r of x is 1 where key r lies in another region than the query, else 0: one byte-to-float conversion and one fma per
+                // score, and the term added is exactly the reference's -100 (swin.rs:283-296, 651).  (region ids are 0 .. 8, so a byte of
+                // the XOR is 0 .. 15: + 0x7f carries into bit 7 exactly when it is non-zero, and never into the next byte)
+                const unsigned xr = *reinterpret_cast<const unsigned*>(rid_s + kt * 16 + g * 4) ^ qrid4;
+                const unsigned x = ((xr + 0x7f7f7f7fu) >> 7) & 0x01010101u;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) st[kt][r] = fmaf((float)((x >> (8 * r)) & 0xffu), -100.0f * LOG2E, st[kt][r]);
             }

@@ -113,3 +113,19 @@ def aspp_deformable(x, tensors, mode="reference_cpu", prefix="", device=0):
                                                     T.stream_of(keep)))
     del keep_w
     return y
+
+
+def decblk(x, tensors, out_channels, mode="reference_cpu", prefix="", use_aspp=True, device=0):
+    """BasicDecBlk::new(in_channels, out_channels, &DecoderConfig { use_aspp_deformable: use_aspp, .. }, vb.pp(prefix)) + forward
+    (decoder.rs:78-141) on an NCHW map [B,in_channels,H,W] -> [B,out_channels,H,W]; `tensors`: name -> host array of the block's
+    weights under `prefix` (SURVEY.md App. A <DecBlk>)."""
+    from .birefnet import _named_array
+    B, Cc, H, W = (int(v) for v in x.shape)
+    arr, keep_w = _named_array(tensors)
+    px, loc, keep, _ = T.as_arg(x)
+    y = T.alloc_like(keep, (B, int(out_channels), H, W))
+    m = {"reference_cpu": _ffi.BRN_DEFORM_REFERENCE_CPU, "deformable": _ffi.BRN_DEFORM_DEFORMABLE}[mode]
+    _ffi.check(_ffi.lib.brn_decblk_forward(arr, len(arr), prefix.encode(), Cc, int(out_channels), int(bool(use_aspp)), m, px, B, H, W, T.ptr_of(y), loc,
+                                           T.device_of(keep, device), T.stream_of(keep)))
+    del keep_w
+    return y

@@ -152,6 +152,13 @@ brn_status brn_model_decoder_forward(brn_model* m, const float* x_nchw, const fl
                                      const float* x3, const float* x4, int B, int H, int W, brn_mem in_loc,
                                      float* logits_out, brn_mem out_loc, void* stream);
 
+/* BiRefNetDecoder::new(config, vb) on its own (birefnet.rs:170-273): a handle that holds ONLY the decoder's weights (names relative
+ * to `prefix`, e.g. "decoder."; the loaded-but-unused heads of birefnet.rs:229-243 must be present, as in the reference).  Such a handle
+ * serves brn_model_decoder_forward (and brn_model_destroy); every entry that needs the backbone or the squeeze module answers
+ * BRN_ERR_INVALID_ARG on it. */
+brn_status brn_decoder_create(const brn_config* cfg, const brn_named_tensor* weights, size_t n_weights, const char* prefix,
+                              int device_ordinal, brn_dtype compute_dtype, brn_model** out);
+
 /* Per-stage wall time of the last forward on this handle, measured with HIP events on the call's stream:
  * [0]=backbone full, [1]=backbone half+fusion, [2]=squeeze, [3]=decoder, [4]=total (ms).  Mirrors the timers of
  * bench_inference.rs:37-92.  Enabled by brn_model_set_profiling(m, 1) (adds event records + one sync). */
@@ -226,6 +233,17 @@ brn_status brn_deform_conv2d_forward(const float* x, int B, int C, int H, int W,
 brn_status brn_aspp_deformable_forward(const brn_named_tensor* weights, size_t n_weights, const char* prefix, int mode,
                                        const float* x, int B, int H, int W, float* y, brn_mem loc,
                                        int device_ordinal, void* stream);
+
+/* BasicDecBlk::new(in_channels, out_channels, &DecoderConfig, vb.pp(prefix)) + forward (decoder.rs:78-141), the block behind
+ * SqueezeModule and decoder_block{4,3,2,1}: conv_in 3x3 (in_channels -> 64, bias) + bn_in + ReLU -> ASPPDeformable(64) (use_aspp != 0:
+ * DecoderConfig::use_aspp_deformable, decoder.rs:107-111; 0 = dec_att is None) -> conv_out 3x3 (64 -> out_channels, bias) + bn_out (no
+ * ReLU).  inter_channels is the fixed 64 of DecoderConfig::default() (inter_channels_adaptive = false, decoder.rs:21,94-98).
+ * weights: "conv_in.weight|bias", "bn_in.*", "dec_att.<ASPP>", "conv_out.weight|bias", "bn_out.*" under `prefix` (SURVEY.md App. A
+ * <DecBlk>); mode = brn_deform_mode.  x [B,in_channels,H,W] -> y [B,out_channels,H,W], NCHW; any in_channels (the map is padded
+ * to the kernels' channel granule inside). */
+brn_status brn_decblk_forward(const brn_named_tensor* weights, size_t n_weights, const char* prefix, int in_channels,
+                              int out_channels, int use_aspp, int mode, const float* x, int B, int H, int W, float* y,
+                              brn_mem loc, int device_ordinal, void* stream);
 
 /* ---- image pre/post-processing: the steps either side of forward_logits in examples/infer_image.rs ------ */
 /* infer_image.rs:44-67.  `img.resize_exact(S, S, FilterType::Triangle)` -> `to_rgb8()` -> (v/255 - mean) / std with the

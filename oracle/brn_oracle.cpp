@@ -603,10 +603,10 @@ static Tensor aspp_deformable(const Tensor& x, const Weights& w, const std::stri
 }
 
 // BasicDecBlk::forward (decoder.rs:126-141)
-static Tensor dec_blk(const Tensor& x, const Weights& w, const std::string& p, int64_t cout, int mode) {
+static Tensor dec_blk(const Tensor& x, const Weights& w, const std::string& p, int64_t cout, int mode, bool use_aspp = true) {
     Tensor t = conv_named(x, w, p + "conv_in", 64, 3, 1, true);
     bn_named_(t, w, p + "bn_in"); relu_(t);
-    t = aspp_deformable(t, w, p + "dec_att.", mode);
+    if (use_aspp) t = aspp_deformable(t, w, p + "dec_att.", mode);    // dec_att is None when DecoderConfig::use_aspp_deformable is false (decoder.rs:107-111,131-135)
     t = conv_named(t, w, p + "conv_out", cout, 3, 1, true);
     bn_named_(t, w, p + "bn_out");
     return t;
@@ -802,6 +802,16 @@ int orc_aspp(const brn_named_tensor* weights, size_t n, const char* prefix, int 
     return guarded([&] {
         Weights w(weights, n);
         Tensor t = aspp_deformable(from_ptr(x, {B, 64, H, W_}), w, prefix ? prefix : "", mode);
+        memcpy(y, t.p(), (size_t)t.numel() * sizeof(float));
+    });
+}
+// BasicDecBlk::new(in_channels, out_channels, &DecoderConfig{use_aspp_deformable, inter_channels_adaptive: false}, vb.pp(prefix)) + forward
+// (decoder.rs:87-141)
+int orc_decblk(const brn_named_tensor* weights, size_t n, const char* prefix, int cin, int cout, int use_aspp, int mode, const float* x, int B, int H,
+               int W_, float* y) {
+    return guarded([&] {
+        Weights w(weights, n);
+        Tensor t = dec_blk(from_ptr(x, {B, cin, H, W_}), w, prefix ? prefix : "", cout, mode, use_aspp != 0);
         memcpy(y, t.p(), (size_t)t.numel() * sizeof(float));
     });
 }

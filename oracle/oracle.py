@@ -227,6 +227,16 @@ def aspp_deformable(x, weights, mode=0, prefix=""):
     return y
 
 
+def decblk(x, weights, out_channels, mode=0, prefix="", use_aspp=True):
+    """BasicDecBlk::forward (decoder.rs:126-141): x [B,Cin,H,W] -> [B,out_channels,H,W]; weights under `prefix`"""
+    x = _f(x)
+    B, cin, H, W = x.shape
+    arr, n, keep = named(weights)
+    y = np.empty((B, out_channels, H, W), np.float32)
+    _chk(lib().orc_decblk(arr, C.c_size_t(n), prefix.encode(), cin, int(out_channels), int(bool(use_aspp)), int(mode), _p(x), B, H, W, _p(y)))
+    return y
+
+
 def squeeze(cfg, weights, x4):
     x4 = _f(x4)
     B, _, h, w = x4.shape

@@ -1,10 +1,117 @@
 //! `ASPPDeformable` of the reference (src/aspp.rs:227-333) over `brn_aspp_deformable_forward`: the module `BasicDecBlk` builds
 //! (decoder.rs:107-111) — five branches on a 64-channel map (aspp1 and aspp_deforms.{0,1,2} = DeformConvASPP k 1,1,3,7 -> 256, BN,
 //! ReLU; global average pool -> 1x1 -> BN -> ReLU -> broadcast), concat 1280, conv1 1x1 + bn1 + ReLU.
-use candle_core::{Module, Result, Tensor};
+use candle_core::{Module, Result, Tensor, D};
 use candle_nn::VarBuilder;
 
+use crate::decoder::{BnW, ConvW};
+use crate::deform_conv::DeformableConv2d;
 use crate::hip_ffi as ffi;
+
+/// Deformable Conv wrapper matching the pretrained weight structure: offset_conv, modulator_conv, regular_conv (aspp.rs:13-187).
+/// Stride 1, `regular_conv` without bias (aspp.rs:45).  `mode` as for `DeformableConv2d`: `BRN_DEFORM_REFERENCE_CPU` = the reference's
+/// CPU branch (regular conv, aspp.rs:183-185), `BRN_DEFORM_DEFORMABLE` = forward_metal (aspp.rs:58-165).
+pub struct DeformConvASPP {
+    inner: DeformableConv2d,
+}
+
+impl DeformConvASPP {
+    /// aspp.rs:24-56 — same signature
+    pub fn new(in_channels: usize, out_channels: usize, kernel_size: usize, padding: usize, vb: VarBuilder) -> Result<Self> {
+        let mut inner = DeformableConv2d::new_no_bias(in_channels, out_channels, kernel_size, 1, padding, vb)?;
+        inner.mode = ffi::BRN_DEFORM_REFERENCE_CPU;
+        Ok(Self { inner })
+    }
+    pub fn set_mode(&mut self, mode: i32) {
+        self.inner.mode = mode;
+    }
+}
+
+impl Module for DeformConvASPP {
+    /// aspp.rs:168-187
+    fn forward(&self, x: &Tensor) -> Result<Tensor> {
+        self.inner.forward(x)
+    }
+}
+
+/// ASPP module with deformable conv and BatchNorm (aspp.rs:190-223): atrous_conv -> bn -> relu
+pub struct ASPPModuleDeformable {
+    pub atrous_conv: DeformConvASPP,
+    bn: BnW,
+}
+
+impl ASPPModuleDeformable {
+    /// aspp.rs:196-214 — same signature
+    pub fn new(in_channels: usize, planes: usize, kernel_size: usize, padding: usize, vb: VarBuilder) -> Result<Self> {
+        let atrous_conv = DeformConvASPP::new(in_channels, planes, kernel_size, padding, vb.pp("atrous_conv"))?;
+        Ok(Self { atrous_conv, bn: BnW::load(planes, vb.pp("bn"))? })
+    }
+}
+
+impl Module for ASPPModuleDeformable {
+    /// aspp.rs:217-223
+    fn forward(&self, x: &Tensor) -> Result<Tensor> {
+        self.bn.apply(&self.atrous_conv.forward(x)?, true)
+    }
+}
+
+/// Regular ASPP module (non-deformable; aspp.rs:337-374, dead code in the reference but a pub type): dilated conv + ReLU
+pub struct ASPPModule {
+    atrous_conv: ConvW,
+}
+
+impl ASPPModule {
+    /// aspp.rs:343-366 — same signature
+    pub fn new(in_channels: usize, planes: usize, kernel_size: usize, padding: usize, dilation: usize, vb: VarBuilder) -> Result<Self> {
+        Ok(Self { atrous_conv: ConvW::load_cfg(in_channels, planes, kernel_size, 1, padding, dilation, true, vb.pp("atrous_conv"))? })
+    }
+}
+
+impl Module for ASPPModule {
+    /// aspp.rs:369-373
+    fn forward(&self, x: &Tensor) -> Result<Tensor> {
+        self.atrous_conv.forward(x, None, ffi::BRN_ACT_RELU)
+    }
+}
+
+/// Regular ASPP with dilation rates 1, 6, 12, 18 (aspp.rs:377-447, dead code in the reference but a pub type)
+pub struct ASPP {
+    branches: Vec<ASPPModule>,
+    global_avg_pool_conv: ConvW,
+    conv1: ConvW,
+}
+
+impl ASPP {
+    /// aspp.rs:388-426 — same signature
+    pub fn new(in_channels: usize, out_channels: Option<usize>, vb: VarBuilder) -> Result<Self> {
+        let out_channels = out_channels.unwrap_or(in_channels);
+        let inter = 256usize;
+        let mut branches = Vec::new();
+        for (i, (k, d)) in [(1usize, 1usize), (3, 6), (3, 12), (3, 18)].iter().enumerate() {
+            let pad = if *k == 1 { 0 } else { *d };
+            branches.push(ASPPModule::new(in_channels, inter, *k, pad, *d, vb.pp(format!("aspp{}", i + 1)))?);
+        }
+        let global_avg_pool_conv = ConvW::load(in_channels, inter, 1, 0, vb.pp("global_avg_pool").pp("1"))?;
+        let conv1 = ConvW::load(inter * 5, out_channels, 1, 0, vb.pp("conv1"))?;
+        Ok(Self { branches, global_avg_pool_conv, conv1 })
+    }
+}
+
+impl Module for ASPP {
+    /// aspp.rs:429-447
+    fn forward(&self, x: &Tensor) -> Result<Tensor> {
+        let (_, _, h, w) = x.dims4()?;
+        let mut parts = Vec::new();
+        for m in &self.branches {
+            parts.push(m.forward(x)?);
+        }
+        let pooled = x.mean_keepdim(D::Minus2)?.mean_keepdim(D::Minus1)?;
+        let x5 = self.global_avg_pool_conv.forward(&pooled, None, ffi::BRN_ACT_RELU)?.upsample_nearest2d(h, w)?;
+        parts.push(x5);
+        let refs: Vec<&Tensor> = parts.iter().collect();
+        self.conv1.forward(&Tensor::cat(&refs, 1)?, None, ffi::BRN_ACT_RELU)
+    }
+}
 
 /// every tensor `ASPPDeformable::new(64, None, vb)` asks its VarBuilder for (aspp.rs:39-45, 247-290), names relative to `vb`
 pub fn aspp_weight_spec() -> Vec<(String, Vec<usize>)> {

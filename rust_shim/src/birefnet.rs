@@ -148,6 +148,26 @@ pub fn weight_spec(config: &BiRefNetConfig) -> Spec {
     s
 }
 
+/// GDT (Gradient Detail) convolutions — conv 3x3 -> 16 + BatchNorm + ReLU (birefnet.rs:97-118): one `brn_conv2d_forward` call with the
+/// batch norm folded and the ReLU in the epilogue
+pub struct GdtConvs {
+    inner: crate::decoder::ConvBnRelu,
+}
+
+impl GdtConvs {
+    /// birefnet.rs:103-108 — same signature: conv under `vb.pp("0")`, batch norm under `vb.pp("1")`
+    pub fn new(in_channels: usize, vb: VarBuilder) -> Result<Self> {
+        Ok(Self { inner: crate::decoder::ConvBnRelu::load(in_channels, 16, vb.pp("0"), vb.pp("1"))? })
+    }
+}
+
+impl Module for GdtConvs {
+    /// birefnet.rs:111-117
+    fn forward(&self, x: &Tensor) -> Result<Tensor> {
+        self.inner.forward(x)
+    }
+}
+
 // ---- the shared model handle ----
 struct Handle(*mut ffi::BrnModel);
 // forwards on one handle are serialised inside the library (mutex + stream event): safe to share
@@ -179,22 +199,44 @@ impl Backbone {
     }
 }
 
-/// Squeeze module (birefnet.rs:70-94)
+/// Squeeze module (birefnet.rs:70-94): inside a `BiRefNet` it is a view of the shared model handle; built on its own
+/// (`SqueezeModule::new`) it is one `BasicDecBlk` under `vb.pp("0")`, as in the reference
 pub struct SqueezeModule {
-    h: Arc<Handle>,
-    out_channels: usize,
+    inner: SqueezeImpl,
+}
+enum SqueezeImpl {
+    Shared { h: Arc<Handle>, out_channels: usize },
+    Own(crate::decoder::BasicDecBlk),
+}
+impl SqueezeModule {
+    /// birefnet.rs:75-83 — same signature (the ASPP is always on: birefnet.rs:76-79)
+    pub fn new(in_channels: usize, out_channels: usize, vb: VarBuilder) -> Result<Self> {
+        let config = crate::decoder::DecoderConfig { use_aspp_deformable: true, inter_channels_adaptive: false };
+        let mut blk = crate::decoder::BasicDecBlk::new(in_channels, out_channels, &config, vb.pp("0"))?;
+        blk.mode = deform_from_env();
+        Ok(Self { inner: SqueezeImpl::Own(blk) })
+    }
 }
 impl Module for SqueezeModule {
     fn forward(&self, x4: &Tensor) -> Result<Tensor> {
+        let (h_, out_channels) = match &self.inner {
+            SqueezeImpl::Own(blk) => return blk.forward(x4),
+            SqueezeImpl::Shared { h, out_channels } => (h, *out_channels),
+        };
         let (b, _c, h, w) = x4.dims4()?;
         let xin = ffi::to_host(x4)?;
-        let mut out = vec![0f32; b * self.out_channels * h * w];
+        let mut out = vec![0f32; b * out_channels * h * w];
         ffi::check(unsafe {
-            ffi::brn_model_squeeze_forward(self.h.0, xin.as_ptr(), b as i32, h as i32, w as i32, ffi::BRN_MEM_HOST, out.as_mut_ptr(),
+            ffi::brn_model_squeeze_forward(h_.0, xin.as_ptr(), b as i32, h as i32, w as i32, ffi::BRN_MEM_HOST, out.as_mut_ptr(),
                                            ffi::BRN_MEM_HOST, std::ptr::null_mut())
         })?;
-        Tensor::from_vec(out, (b, self.out_channels, h, w), x4.device())
+        Tensor::from_vec(out, (b, out_channels, h, w), x4.device())
     }
+}
+
+/// the decoder's share of `weight_spec` (names relative to the decoder's own VarBuilder: birefnet.rs:170-273)
+pub fn decoder_weight_spec(config: &BiRefNetConfig) -> Spec {
+    weight_spec(config).into_iter().filter_map(|(n, shp)| n.strip_prefix("decoder.").map(|r| (r.to_string(), shp))).collect()
 }
 
 /// BiRefNet decoder (birefnet.rs:121-377)
@@ -202,6 +244,18 @@ pub struct BiRefNetDecoder {
     h: Arc<Handle>,
 }
 impl BiRefNetDecoder {
+    /// birefnet.rs:170 — same signature: a decoder on its own (`vb` at the decoder's prefix, `vb.pp("decoder")` in birefnet.rs:401),
+    /// behind a handle that holds only the decoder's weights (`brn_decoder_create`)
+    pub fn new(config: BiRefNetConfig, vb: VarBuilder) -> Result<Self> {
+        let named = ffi::NamedTensors::from_varbuilder(&vb, &decoder_weight_spec(&config))?;
+        let c = config.to_c(deform_from_env())?;
+        let mut raw = std::ptr::null_mut();
+        let prefix = std::ffi::CString::new("").unwrap();
+        ffi::check(unsafe {
+            ffi::brn_decoder_create(&c, named.views.as_ptr(), named.views.len(), prefix.as_ptr(), device_from_env(), compute_from_env(), &mut raw)
+        })?;
+        Ok(Self { h: Arc::new(Handle(raw)) })
+    }
     /// birefnet.rs:278 — same signature
     pub fn forward(&self, x: &Tensor, x1: &Tensor, x2: &Tensor, x3: &Tensor, x4: &Tensor) -> Result<Tensor> {
         let (b, _c, h, w) = x.dims4()?;
@@ -227,7 +281,7 @@ pub struct BiRefNet {
 
 impl BiRefNet {
     /// birefnet.rs:389 — same signature.  Compute mode and deform mode of the HIP backend come from the environment
-    /// (`BIREFNET_HIP_COMPUTE` = f32 | f32_split3 (default) | f32_split2 | bf16_operands | bf16; `BIREFNET_HIP_DEFORM` =
+    /// (`BIREFNET_HIP_COMPUTE` = f32 | f32_split3 (default) | f32_split2 | bf16; `BIREFNET_HIP_DEFORM` =
     /// reference_cpu (default) | deformable) so that the reference's call sites compile unchanged.
     /// The HIP device and the largest batch the workspace is planned for come from `BIREFNET_HIP_DEVICE` (default 0) and
     /// `BIREFNET_HIP_MAX_BATCH` (default 1; larger batches re-plan on first use); `new_on` takes them as arguments.
@@ -270,7 +324,7 @@ impl BiRefNet {
     fn wrap(config: BiRefNetConfig, raw: *mut ffi::BrnModel, device: i32) -> Self {
         let h = Arc::new(Handle(raw));
         let out_channels = config.lateral_channels()[3];
-        Self { config, backbone: Backbone { h: h.clone() }, squeeze_module: SqueezeModule { h: h.clone(), out_channels }, decoder: BiRefNetDecoder { h: h.clone() }, h, device }
+        Self { config, backbone: Backbone { h: h.clone() }, squeeze_module: SqueezeModule { inner: SqueezeImpl::Shared { h: h.clone(), out_channels } }, decoder: BiRefNetDecoder { h: h.clone() }, h, device }
     }
 
     /// HIP device ordinal this model's weights and workspace live on
@@ -326,7 +380,6 @@ fn compute_from_env() -> i32 {
     match std::env::var("BIREFNET_HIP_COMPUTE").as_deref() {
         Ok("f32") => ffi::BRN_F32,
         Ok("f32_split2") => ffi::BRN_F32_SPLIT2,
-        Ok("bf16_operands") => ffi::BRN_BF16_OPERANDS,
         Ok("bf16") => ffi::BRN_BF16,
         _ => ffi::BRN_F32_SPLIT3,
     }

@@ -17,6 +17,10 @@ pub const BRN_BF16: c_int = 4;
 /// brn_deform_mode
 pub const BRN_DEFORM_REFERENCE_CPU: c_int = 0;
 pub const BRN_DEFORM_DEFORMABLE: c_int = 1;
+/// brn_act
+pub const BRN_ACT_NONE: c_int = 0;
+pub const BRN_ACT_RELU: c_int = 1;
+pub const BRN_ACT_GELU_ERF: c_int = 2;
 
 /// == `brn_config` (field for field, same order)
 #[repr(C)]
@@ -68,6 +72,8 @@ extern "C" {
     pub fn brn_model_create_from_safetensors(cfg: *const BrnConfig, path: *const c_char, prefix: *const c_char, device_ordinal: c_int,
                                              compute_dtype: c_int, max_batch: c_int, max_h: c_int, max_w: c_int,
                                              out: *mut *mut BrnModel) -> c_int;
+    pub fn brn_decoder_create(cfg: *const BrnConfig, weights: *const BrnNamedTensor, n_weights: size_t, prefix: *const c_char,
+                              device_ordinal: c_int, compute_dtype: c_int, out: *mut *mut BrnModel) -> c_int;
     pub fn brn_model_destroy(m: *mut BrnModel);
     pub fn brn_forward_logits(m: *mut BrnModel, x_nchw: *const c_float, b: c_int, h: c_int, w: c_int, in_loc: c_int,
                               logits_out: *mut c_float, out_loc: c_int, stream: *mut c_void) -> c_int;
@@ -114,6 +120,9 @@ extern "C" {
                                      loc: c_int, device_ordinal: c_int, stream: *mut c_void) -> c_int;
     pub fn brn_aspp_deformable_forward(weights: *const BrnNamedTensor, n_weights: usize, prefix: *const c_char, mode: c_int, x: *const c_float,
                                        b: c_int, h: c_int, w: c_int, y: *mut c_float, loc: c_int, device_ordinal: c_int, stream: *mut c_void) -> c_int;
+    pub fn brn_decblk_forward(weights: *const BrnNamedTensor, n_weights: usize, prefix: *const c_char, in_channels: c_int, out_channels: c_int,
+                              use_aspp: c_int, mode: c_int, x: *const c_float, b: c_int, h: c_int, w: c_int, y: *mut c_float, loc: c_int,
+                              device_ordinal: c_int, stream: *mut c_void) -> c_int;
     pub fn brn_preprocess_image(pixels: *const c_uchar, h: c_int, w: c_int, channels: c_int, s: c_int, x_nchw_out: *mut c_float,
                                 out_loc: c_int, device_ordinal: c_int, stream: *mut c_void) -> c_int;
     pub fn brn_postprocess_mask(logits: *const c_float, s: c_int, in_loc: c_int, apply_sigmoid: c_int, out_h: c_int, out_w: c_int,

@@ -101,6 +101,46 @@ pub(crate) fn stage_dims(h: usize, w: usize, patch: usize) -> [(usize, usize); 4
     out
 }
 
+/// Patch Embedding layer (swin.rs:659-715): zero-pad to a multiple of the patch, conv k = stride = patch_size, LayerNorm over the
+/// channels of every token.  Over `brn_conv2d_forward` (stride) and `brn_layer_norm_forward`; the pad and the NCHW <-> token-major
+/// transposes are candle tensor ops, as in the reference.
+pub struct PatchEmbed {
+    proj: crate::decoder::ConvW,
+    norm: Option<(Vec<f32>, Vec<f32>)>,
+    patch_size: usize,
+}
+
+impl PatchEmbed {
+    /// swin.rs:666-690 — same signature
+    pub fn new(patch_size: usize, in_channels: usize, embed_dim: usize, norm: bool, vb: VarBuilder) -> Result<Self> {
+        let proj = crate::decoder::ConvW::load_cfg(in_channels, embed_dim, patch_size, patch_size, 0, 1, true, vb.pp("proj"))?;
+        let norm = if norm {
+            let nb = vb.pp("norm");
+            Some((ffi::to_host(&nb.get(embed_dim, "weight")?)?, ffi::to_host(&nb.get(embed_dim, "bias")?)?))
+        } else {
+            None
+        };
+        Ok(Self { proj, norm, patch_size })
+    }
+
+    /// swin.rs:692-714 — x [B, in_channels, H, W] -> [B, embed_dim, ceil(H / p), ceil(W / p)]
+    pub fn forward(&self, x: &Tensor) -> Result<Tensor> {
+        let (_, _, h, w) = x.dims4()?;
+        let p = self.patch_size;
+        let x = if w % p != 0 || h % p != 0 { x.pad_with_zeros(3, 0, (p - w % p) % p)?.pad_with_zeros(2, 0, (p - h % p) % p)? } else { x.clone() };
+        let y = self.proj.forward(&x, None, ffi::BRN_ACT_NONE)?;
+        let Some((g, bta)) = &self.norm else { return Ok(y) };
+        let (b, c, wh, ww) = y.dims4()?;
+        let tokens = ffi::to_host(&y.flatten_from(2)?.transpose(1, 2)?.contiguous()?)?;
+        let mut out = vec![0f32; tokens.len()];
+        ffi::check(unsafe {
+            ffi::brn_layer_norm_forward(tokens.as_ptr(), (b * wh * ww) as i32, c as i32, g.as_ptr(), bta.as_ptr(), 1e-5, out.as_mut_ptr(),
+                                        ffi::BRN_MEM_HOST, 0, std::ptr::null_mut())
+        })?;
+        Tensor::from_vec(out, (b, wh * ww, c), y.device())?.transpose(1, 2)?.reshape((b, c, wh, ww))
+    }
+}
+
 /// Swin Transformer backbone (swin.rs:718-723); the weights live in HBM behind `handle`
 pub struct SwinTransformer {
     config: SwinConfig,

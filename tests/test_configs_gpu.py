@@ -16,6 +16,15 @@ GOLD = os.path.join(HERE, "golden")
 # bf16 modes are throughput modes: the fp32 gate (1e-3 abs | 1e-2 rel) does not apply; their error against the fp64 / fp32
 # restatement is REPORTED and bounded here.  |logit| max of the 1024^2 synthetic run is ~2.2.
 BF16_ABS_BOUND = {"bf16": 2.4e-2}   # 3x the largest error measured on MI355X: 6.4e-3 (1024^2), 7.9e-3 (2048^2, deformable)
+# the same in mask space (forward() = sigmoid(logits), birefnet.rs:466-469; north_star: "masks within 1e-3 of reference" — an fp32
+# criterion): sigmoid' <= 1/4, so a logit error e is a mask error <= e / 4
+BF16_MASK_BOUND = 0.25 * BF16_ABS_BOUND["bf16"]
+
+
+def _mask_err(m, x, gold_logits, stride):
+    """max |forward(x)[0] - sigmoid(golden logits)| on the strided golden of image 0"""
+    p = m.forward(x[:1]).cpu().numpy().astype(np.float64)[0, :, ::stride, ::stride]
+    return float(np.abs(p - 1.0 / (1.0 + np.exp(-gold_logits.astype(np.float64)))).max())
 
 
 def _full_model(mode, max_batch=0, size=0):
@@ -41,8 +50,9 @@ def test_c3_batch8_1024_bf16(gpu, mode):
     e0 = float(np.abs(yn[0, :, ::16, ::16] - k["m1024_full_ref_s16"][0]).max())
     alone = [m.forward_logits(x[b:b + 1]).cpu().numpy().astype(np.float64)[0] for b in (0, 5)]
     d = max(float(np.abs(alone[0] - yn[0]).max()), float(np.abs(alone[1] - yn[5]).max()))
-    print(f"c3 [{mode}] B=8 1024^2: max abs err of image 0 vs the fp64 golden {e0:.3e}; image alone vs in batch {d:.3e}")
-    assert e0 < BF16_ABS_BOUND[mode] and d < BF16_ABS_BOUND[mode]
+    em = _mask_err(m, x, k["m1024_full_ref_s16"][0], 16)
+    print(f"c3 [{mode}] B=8 1024^2: max abs err of image 0 vs the fp64 golden {e0:.3e} (mask space {em:.3e}); image alone vs in batch {d:.3e}")
+    assert e0 < BF16_ABS_BOUND[mode] and d < BF16_ABS_BOUND[mode] and em < BF16_MASK_BOUND
     # the images of the batch are different images (seeds 1000..1007): a stuck batch index would show here
     assert float(np.abs(yn[1] - yn[0]).max()) > 0.1
     m.close()
@@ -86,8 +96,9 @@ def test_c3_batch8_1024_bf16_deformable(gpu):
     yn = y.cpu().numpy().astype(np.float64)
     e0 = float(np.abs(yn[0, :, ::16, ::16] - k["m1024_full_def_s16"][0]).max())
     d = float(np.abs(m.forward_logits(x[5:6]).cpu().numpy().astype(np.float64)[0] - yn[5]).max())
-    print(f"c3 deformable [bf16] B=8 1024^2: max abs err of image 0 vs the fp64 golden {e0:.3e}; image alone vs in batch {d:.3e}")
-    assert e0 < BF16_ABS_BOUND["bf16"] and d < BF16_ABS_BOUND["bf16"]
+    em = _mask_err(m, x, k["m1024_full_def_s16"][0], 16)
+    print(f"c3 deformable [bf16] B=8 1024^2: max abs err of image 0 vs the fp64 golden {e0:.3e} (mask space {em:.3e}); image alone vs in batch {d:.3e}")
+    assert e0 < BF16_ABS_BOUND["bf16"] and d < BF16_ABS_BOUND["bf16"] and em < BF16_MASK_BOUND
     m.close()
 
 
@@ -100,8 +111,9 @@ def test_c5_batch4_2048_bf16_deformable(gpu):
     y = m.forward_logits(x)
     assert torch.isfinite(y).all() and torch.equal(y, m.forward_logits(x))
     e0 = float(np.abs(y.cpu().numpy().astype(np.float64)[0, :, ::32, ::32] - k["m2048_full_def_s32"][0]).max())
-    print(f"c5 deformable [bf16] B=4 2048^2: max abs err of image 0 vs the fp32 golden {e0:.3e}")
-    assert e0 < BF16_ABS_BOUND["bf16"]
+    em = _mask_err(m, x, k["m2048_full_def_s32"][0], 32)
+    print(f"c5 deformable [bf16] B=4 2048^2: max abs err of image 0 vs the fp32 golden {e0:.3e} (mask space {em:.3e})")
+    assert e0 < BF16_ABS_BOUND["bf16"] and em < BF16_MASK_BOUND
     m.close()
 
 
@@ -134,8 +146,9 @@ def test_c5_batch4_2048_bf16(gpu, mode):
     yn = y.cpu().numpy().astype(np.float64)
     e0 = float(np.abs(yn[0, :, ::32, ::32] - k["m2048_full_ref_s32"][0]).max())
     d = float(np.abs(m.forward_logits(x[3:4]).cpu().numpy().astype(np.float64)[0] - yn[3]).max())
-    print(f"c5 [{mode}] B=4 2048^2: max abs err of image 0 vs the fp32 golden {e0:.3e}; image alone vs in batch {d:.3e}")
-    assert e0 < BF16_ABS_BOUND[mode] and d < BF16_ABS_BOUND[mode]
+    em = _mask_err(m, x, k["m2048_full_ref_s32"][0], 32)
+    print(f"c5 [{mode}] B=4 2048^2: max abs err of image 0 vs the fp32 golden {e0:.3e} (mask space {em:.3e}); image alone vs in batch {d:.3e}")
+    assert e0 < BF16_ABS_BOUND[mode] and d < BF16_ABS_BOUND[mode] and em < BF16_MASK_BOUND
     m.close()
 
 
@@ -224,3 +237,37 @@ def test_odd_sizes_and_batches_bf16_tracks_fp32_equivalent(gpu, deform):
         assert d < BF16_ABS_BOUND["bf16"], (H, W, B, d)
     for m in ms.values():
         m.close()
+
+
+def test_sub_batch_workspace_is_planned_for_the_part_and_falls_back(gpu, tmp_path):
+    """a device-resident batch runs as two sub-batches with a workspace each; every workspace is sized by a dry run of the PART
+    (not of the whole batch), and when the second workspace cannot be allocated (BRN_FAULT_SIDE_ARENA: the test hook that makes that
+    hipMalloc fail) the batch runs as one part on one stream instead of failing.  Child processes: the switches are read per process."""
+    import subprocess
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "import candle_birefnet_amd as cb\n"
+        "cfg = cb.BiRefNetConfig(); cfg.swin.depths = [2, 2, 2, 2]\n"
+        "w = cb.synth_weights(cb.birefnet_weight_spec(cfg), seed=42)\n"
+        "m = cb.BiRefNet.new(cfg, cb.VarBuilder.from_tensors(w), compute='bf16', max_batch=6, max_size=(256, 256))\n"
+        "x = torch.from_numpy(cb.synth_input(6, 256, 256)).cuda()\n"
+        "free0 = torch.cuda.mem_get_info()[0]\n"
+        "y = m.forward_logits(x); torch.cuda.synchronize()\n"
+        "assert torch.equal(y, m.forward_logits(x))\n"
+        "y5 = m.forward_logits(x[:5])            # parts of 3 + 2 images: the larger part was planned\n"
+        "np.savez(sys.argv[1], y=y.cpu().numpy(), y5=y5.cpu().numpy(), grew=np.int64(free0 - torch.cuda.mem_get_info()[0]))\n") % ROOT
+    outs = {}
+    for tag, env in (("split", {}), ("fallback", {"BRN_FAULT_SIDE_ARENA": "1"}), ("one", {"BRN_SPLIT_STREAMS": "1"})):
+        out = str(tmp_path / f"{tag}.npz")
+        pr = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert pr.returncode == 0, pr.stderr[-2000:]
+        outs[tag] = np.load(out)
+    # the fallback IS the one-stream path: same plans, same bits
+    np.testing.assert_array_equal(outs["fallback"]["y"], outs["one"]["y"])
+    np.testing.assert_array_equal(outs["fallback"]["y5"], outs["one"]["y5"])
+    # two parts compute the same images with the plans of a smaller M: equal up to the mode's rounding
+    assert np.abs(outs["split"]["y"] - outs["one"]["y"]).max() < BF16_ABS_BOUND["bf16"]
+    assert np.abs(outs["split"]["y5"] - outs["one"]["y5"]).max() < BF16_ABS_BOUND["bf16"]
+    # the second workspace is allocated at the first split forward and is no larger than a part needs: the device memory taken by the
+    # first forward (side workspace) is at most what the handle reserved at creation for the main one (+ allocator slack)
+    print("device memory taken by the first forward: split %d MB, one stream %d MB" % (outs["split"]["grew"] >> 20, outs["one"]["grew"] >> 20))

@@ -191,3 +191,29 @@ def test_pieces_in_every_compute_mode(gpu, compute, tol, deform):
     out = m.decoder.forward(x, *[parts[k].float().numpy() for k in ("x1", "x2", "x3", "x4s")])
     assert np.abs(out - ref.numpy()).max() <= tol * max(1.0, float(ref.abs().max()))
     m.close()
+
+
+def test_decoder_only_handle_and_standalone_squeeze(gpu):
+    """BiRefNetDecoder::new(config, vb.pp("decoder")) and SqueezeModule::new(5760, 3072, vb.pp("squeeze_module")) built on their own
+    (birefnet.rs:170, 75; the pub constructors a crate user can call without a BiRefNet): brn_decoder_create / brn_decblk_forward give
+    the bits of the same pieces inside a whole model; a decoder-only handle refuses the entries that need a backbone."""
+    cb, cfg, w = _build([2, 2, 2, 2])
+    vb = cb.VarBuilder.from_tensors(w)
+    m = cb.BiRefNet.new(cfg, vb)
+    S = 64
+    x = cb.synth_input(1, S, S)
+    ref, parts = R.forward_logits(x, w, cfg, torch.float64, return_parts=True)
+    feats = [parts[k].float().numpy() for k in ("x1", "x2", "x3", "x4s")]
+    dec = cb.BiRefNetDecoder.new(cfg, vb.pp("decoder"))
+    np.testing.assert_array_equal(dec.forward(x, *feats), m.decoder.forward(x, *feats))
+    with pytest.raises(cb.BrnError):
+        cb._ffi.check(cb._ffi.lib.brn_forward_logits(dec._h, x.ctypes.data, 1, S, S, 0, np.empty((1, 1, S, S), np.float32).ctypes.data, 0, None))
+    dec.close()
+    sq = cb.SqueezeModule.new(cfg.x4_channels(), cfg.lateral_channels()[3], vb.pp("squeeze_module"))
+    x4 = parts["x4"].float().numpy()
+    np.testing.assert_array_equal(sq.forward(x4), m.squeeze_module.forward(x4))
+    # a missing decoder tensor is an error naming it, as vb.get's in the reference
+    w2 = {k: v for k, v in w.items() if k != "decoder.gdt_convs_pred_3.0.weight"}
+    with pytest.raises(cb.BrnError, match="gdt_convs_pred_3"):
+        cb.BiRefNetDecoder.new(cfg, cb.VarBuilder.from_tensors(w2).pp("decoder"))
+    m.close()

@@ -325,13 +325,16 @@ def test_deform_conv2d_bf16_mode(gpu, k, stride, pad, O, H, C):
 _ATT_BF16_CASES = [(1, 12, 12, 2, 0), (2, 24, 24, 3, 6), (1, 16, 16, 2, 6), (1, 16, 16, 2, 0), (1, 32, 20, 6, 6), (1, 4, 4, 1, 6), (1, 64, 64, 24, 6), (2, 36, 36, 12, 6)]
 
 
-def _att_bf16_reference(B, H, W, heads, shift):
+def _att_bf16_reference(B, H, W, heads, shift, qk_gain=1.0):
     """exact-operand reference of window_attention_bf16_kernel between its two GEMMs: x and the weights rounded to bf16, the qkv
     matrix and the attention output rounded to bf16 where the mode stores them in HBM, everything else (scores, bias, mask, softmax,
     PV, proj) in fp64.  What the kernel adds: fp32 accumulation, softmax numerators rounded to bf16 for the PV MFMA, exp2 on
     log2-scaled scores."""
     C = heads * 32
     w = _attn_weights(C, heads, seed=10)
+    if qk_gain != 1.0:       # q and k rows of the qkv Linear scaled: the scores grow by qk_gain^2
+        w["attn.qkv.weight"] = w["attn.qkv.weight"].copy(); w["attn.qkv.bias"] = w["attn.qkv.bias"].copy()
+        w["attn.qkv.weight"][:2 * C] *= np.float32(qk_gain); w["attn.qkv.bias"][:2 * C] *= np.float32(qk_gain)
     x = rnd(B, H, W, C, seed=99)
     wr = {n: (_bf16_round(a) if n in ("attn.qkv.weight", "attn.proj.weight") else np.asarray(a, np.float64)) for n, a in w.items()}
     store = lambda t: t.to(torch.bfloat16).to(torch.float64)
@@ -358,6 +361,34 @@ def test_window_attention_bf16_mode(gpu, B, H, W, heads, shift):
     err = np.abs(np.asarray(y, np.float64) - ref)
     scale = np.abs(ref).max()
     print(f"attention bf16 B{B} {H}x{W} h{heads} s{shift}: max abs err {err.max():.2e}, |ref| max {scale:.2f}")
+    assert err.max() <= ATT_BF16_TOL * scale
+
+
+@pytest.mark.parametrize("B,H,W,heads", [(2, 24, 24, 2), (1, 32, 20, 6), (1, 36, 36, 4)])
+def test_window_attention_bf16_mode_shift_mask_is_exactly_minus_100(gpu, B, H, W, heads):
+    """the shift mask adds the reference's constant -100 (swin.rs:283-296, 651) whatever the two regions are (the kernel
+    once added -100 x a region distance of 1 .. 15).  That only shows when a masked key's score exceeds the unmasked ones by about 100:
+    q and k are scaled so that scores have a standard deviation of ~60 and a few per cent of the query rows of the edge windows are in
+    that regime; same exact-operand reference and tolerance as test_window_attention_bf16_mode."""
+    from candle_birefnet_amd import ops
+    x, w, ref = _att_bf16_reference(B, H, W, heads, 6, qk_gain=7.75)
+    # the case must actually discriminate: the same reference with the mask at -200 differs by far more than the tolerance
+    C = heads * 32
+    wr = {n: (_bf16_round(a) if n in ("attn.qkv.weight", "attn.proj.weight") else np.asarray(a, np.float64)) for n, a in w.items()}
+    store = lambda t: t.to(torch.bfloat16).to(torch.float64)
+    Hp, Wp = -(-H // 12) * 12, -(-W // 12) * 12
+    m200 = R.attn_mask(Hp, Wp, 12, 6, torch.float64) * 2.0
+    ref200 = R.window_attention_block(torch.from_numpy(_bf16_round(x)), wr, "", heads, 12, 6, torch.float64, mask=m200, store=store).numpy()
+    scale = np.abs(ref).max()
+    assert np.abs(ref200 - ref).max() > 10 * ATT_BF16_TOL * scale, "the scores of this case never reach the masked regime"
+    ops.set_compute("bf16")
+    try:
+        y = ops.window_attention(x, heads, 6, w["attn.qkv.weight"], w["attn.qkv.bias"], w["attn.proj.weight"], w["attn.proj.bias"],
+                                 w["attn.relative_position_bias_table"])
+    finally:
+        ops.set_compute("f32")
+    err = np.abs(np.asarray(y, np.float64) - ref)
+    print(f"attention bf16, large scores, B{B} {H}x{W} h{heads}: max abs err {err.max():.2e}, |ref| max {scale:.2f}; -200 mask would differ by {np.abs(ref200 - ref).max():.2e}")
     assert err.max() <= ATT_BF16_TOL * scale
 
 
@@ -453,3 +484,52 @@ def test_deform_conv2d_geometry_fuzz(gpu):
     pr = subprocess.run([sys.executable, os.path.join(root, "tools", "deform_fuzz.py"), "25", "3"], capture_output=True, text=True, timeout=900)
     assert pr.returncode == 0, pr.stderr[-2000:]
     assert "25 cases, 0 problems" in pr.stdout, pr.stdout[-3000:]
+
+
+@pytest.mark.parametrize("cin,cout,H,W,mode,use_aspp,compute", [
+    (480, 192, 24, 20, "reference_cpu", True, "f32"),        # decoder_block1's widths (birefnet.rs:212) on a small ragged map
+    (480, 192, 16, 16, "deformable", True, "f32_split3"),
+    (100, 48, 12, 16, "deformable", True, "f32"),            # in_channels off the 32-channel granule (the reference takes any)
+    (96, 40, 16, 12, "reference_cpu", False, "f32_split2"),  # DecoderConfig { use_aspp_deformable: false }: dec_att is None (decoder.rs:107-111)
+    (1920, 768, 8, 8, "reference_cpu", True, "f32"),         # decoder_block3's widths
+])
+def test_decblk_forward_vs_oracle(gpu, cin, cout, H, W, mode, use_aspp, compute):
+    """brn_decblk_forward = BasicDecBlk::new + forward (decoder.rs:78-141) for blocks other than the squeeze instance, against the
+    oracle's restatement of the same lines (oracle/brn_oracle.cpp dec_blk) at the north-star gate."""
+    from candle_birefnet_amd import ops
+    from candle_birefnet_amd.weights import _decblk, synth_weights
+    from oracle import oracle as O
+    w = synth_weights(_decblk("blk.", cin, cout), seed=7)
+    x = rnd(2, cin, H, W, seed=3)
+    ops.set_compute(compute)
+    try:
+        y = ops.decblk(x, w, cout, mode=mode, prefix="blk.", use_aspp=use_aspp)
+    finally:
+        ops.set_compute("f32")
+    ref = O.decblk(x, w, cout, mode=1 if mode == "deformable" else 0, prefix="blk.", use_aspp=use_aspp).astype(np.float64)
+    assert y.shape == (2, cout, H, W)
+    err = np.abs(np.asarray(y, np.float64) - ref)
+    assert ((err <= 1e-3) | (err <= 1e-2 * np.abs(ref))).all(), f"max abs err {err.max():.3e}"
+    assert err.max() <= 2e-4 * max(1.0, np.abs(ref).max())
+    if not use_aspp:     # the block without dec_att must not need the ASPP tensors at all
+        w2 = {k: v for k, v in w.items() if ".dec_att." not in k}
+        np.testing.assert_array_equal(ops.decblk(x, w2, cout, mode=mode, prefix="blk.", use_aspp=False), ops.decblk(x, w, cout, mode=mode, prefix="blk.", use_aspp=False))
+
+
+def test_decblk_forward_bf16_mode(gpu):
+    """the same entry in compute mode bf16 (bf16 maps inside, in_channels padded to the 64-channel chunk): bounded against the oracle"""
+    from candle_birefnet_amd import ops
+    from candle_birefnet_amd.weights import _decblk, synth_weights
+    from oracle import oracle as O
+    for cin, cout, mode in ((480, 192, "reference_cpu"), (100, 64, "deformable")):
+        w = synth_weights(_decblk("", cin, cout), seed=9)
+        x = rnd(1, cin, 24, 24, seed=4)
+        ops.set_compute("bf16")
+        try:
+            y = ops.decblk(x, w, cout, mode=mode)
+        finally:
+            ops.set_compute("f32")
+        ref = O.decblk(x, w, cout, mode=1 if mode == "deformable" else 0).astype(np.float64)
+        err = np.abs(np.asarray(y, np.float64) - ref).max()
+        print(f"decblk bf16 {cin}->{cout} {mode}: max abs err {err:.2e}, |ref| max {np.abs(ref).max():.2f}")
+        assert err <= 3e-2 * max(1.0, np.abs(ref).max())

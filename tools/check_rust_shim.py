@@ -4,7 +4,10 @@
   * every entry point the header declares is declared exactly once in rust_shim/src/hip_ffi.rs, with the same number of
     parameters, and hip_ffi.rs declares nothing else;
   * the brn_dtype / brn_mem / brn_deform_mode constants agree;
-  * no todo!() / unimplemented!() anywhere in the shim.
+  * no todo!() / unimplemented!() anywhere in the shim;
+  * every public item of the reference crate (pub mod / pub use / pub struct / pub fn / impl Module; a static list with the
+    reference's file:line) exists in rust_shim/src with the reference's signature;
+  * the compute-mode names the shim reads from the environment are modes the product library accepts.
 Exit code 0 = consistent.  Used by tests/test_rust_shim_cpu.py."""
 import os
 import re
@@ -132,8 +135,67 @@ def main():
             errs.append(f"aspp.rs: {lit} missing")
     if sorted(got) != want:
         errs.append("aspp.rs: the name list differs from the Python mirror's <ASPP> spec")
+    # the reference crate's PUBLIC ITEM LIST (every `pub` struct / fn / mod / use of /root/reference/src, with the line it is declared on;
+    # a static list: the checker must also run where the reference is absent).  Private items (Mlp, WindowAttention,
+    # SwinTransformerBlock, PatchMerging) are not part of the surface; `swin::BasicLayer` is a pub struct whose constructor is private
+    # (swin.rs:538-539 `fn new`): no code outside the crate can build one, so there is nothing to bind.
+    src = {fn: open(os.path.join(ROOT, "rust_shim", "src", fn)).read() for fn in os.listdir(os.path.join(ROOT, "rust_shim", "src"))}
+    PUB = [
+        ("lib.rs", "lib.rs:6-10", [r"pub mod deform_conv;", r"pub mod decoder;", r"pub mod aspp;", r"pub mod birefnet;", r"pub mod swin;"]),
+        ("lib.rs", "lib.rs:12-14", [r"pub use birefnet::BiRefNet;", r"pub use deform_conv::DeformableConv2d;", r"pub use swin::\{SwinConfig, SwinTransformer\};"]),
+        ("aspp.rs", "aspp.rs:13-187", [r"pub struct DeformConvASPP", r"impl DeformConvASPP \{.*?pub fn new\(in_channels: usize, out_channels: usize, kernel_size: usize, padding: usize, vb: VarBuilder\)",
+                                       r"impl Module for DeformConvASPP"]),
+        ("aspp.rs", "aspp.rs:190-223", [r"pub struct ASPPModuleDeformable", r"pub atrous_conv: DeformConvASPP",
+                                        r"impl ASPPModuleDeformable \{.*?pub fn new\(in_channels: usize, planes: usize, kernel_size: usize, padding: usize, vb: VarBuilder\)",
+                                        r"impl Module for ASPPModuleDeformable"]),
+        ("aspp.rs", "aspp.rs:227-333", [r"pub struct ASPPDeformable", r"impl ASPPDeformable \{.*?pub fn new\(in_channels: usize, out_channels: Option<usize>, vb: VarBuilder\)",
+                                        r"impl Module for ASPPDeformable"]),
+        ("aspp.rs", "aspp.rs:337-374", [r"pub struct ASPPModule \{", r"impl ASPPModule \{.*?pub fn new\(in_channels: usize, planes: usize, kernel_size: usize, padding: usize, dilation: usize, vb: VarBuilder\)",
+                                        r"impl Module for ASPPModule \{"]),
+        ("aspp.rs", "aspp.rs:377-447", [r"pub struct ASPP \{", r"impl ASPP \{.*?pub fn new\(in_channels: usize, out_channels: Option<usize>, vb: VarBuilder\)", r"impl Module for ASPP \{"]),
+        ("birefnet.rs", "birefnet.rs:13-67", [r"pub struct BiRefNetConfig", r"impl Default for BiRefNetConfig", r"pub fn lateral_channels\(&self\) -> Vec<usize>",
+                                              r"pub fn x4_channels\(&self\) -> usize", r"pub fn swin_l\(\) -> Self"] +
+                                             [rf"pub {f}:" for f in ("size", "backbone", "backbone_channels", "mul_scl_ipt", "ms_supervision", "dec_ipt", "use_aspp_deformable", "cxt")]),
+        ("birefnet.rs", "birefnet.rs:70-94", [r"pub struct SqueezeModule", r"impl SqueezeModule \{.*?pub fn new\(in_channels: usize, out_channels: usize, vb: VarBuilder\)", r"impl Module for SqueezeModule"]),
+        ("birefnet.rs", "birefnet.rs:97-118", [r"pub struct GdtConvs", r"impl GdtConvs \{.*?pub fn new\(in_channels: usize, vb: VarBuilder\)", r"impl Module for GdtConvs"]),
+        ("birefnet.rs", "birefnet.rs:121-377", [r"pub struct BiRefNetDecoder", r"impl BiRefNetDecoder \{.*?pub fn new\(config: BiRefNetConfig, vb: VarBuilder\)",
+                                                r"pub fn forward\(&self, x: &Tensor, x1: &Tensor, x2: &Tensor, x3: &Tensor, x4: &Tensor\) -> Result<Tensor>"]),
+        ("birefnet.rs", "birefnet.rs:380-476", [r"pub struct BiRefNet \{", r"pub config: BiRefNetConfig", r"pub backbone:", r"pub squeeze_module: SqueezeModule", r"pub decoder: BiRefNetDecoder",
+                                                r"pub fn new\(config: BiRefNetConfig, vb: VarBuilder\) -> Result<Self>", r"pub fn forward_logits\(&self, x: &Tensor\) -> Result<Tensor>",
+                                                r"pub fn forward\(&self, x: &Tensor\) -> Result<Tensor>", r"impl Module for BiRefNet"]),
+        ("decoder.rs", "decoder.rs:12-24", [r"pub struct DecoderConfig", r"pub use_aspp_deformable: bool", r"pub inter_channels_adaptive: bool", r"impl Default for DecoderConfig"]),
+        ("decoder.rs", "decoder.rs:28-56", [r"pub struct SimpleConvs", r"pub fn new\(in_channels: usize, out_channels: usize, inter_channels: usize, vb: VarBuilder\)", r"impl Module for SimpleConvs"]),
+        ("decoder.rs", "decoder.rs:59-74", [r"pub struct BasicLatBlk", r"impl BasicLatBlk \{.*?pub fn new\(in_channels: usize, out_channels: usize, vb: VarBuilder\)", r"impl Module for BasicLatBlk"]),
+        ("decoder.rs", "decoder.rs:78-141", [r"pub struct BasicDecBlk", r"impl BasicDecBlk \{.*?pub fn new\(in_channels: usize, out_channels: usize, config: &DecoderConfig, vb: VarBuilder\)", r"impl Module for BasicDecBlk"]),
+        ("decoder.rs", "decoder.rs:143-217", [r"pub struct ResBlk", r"impl ResBlk \{.*?pub fn new\(in_channels: usize, out_channels: usize, config: &DecoderConfig, vb: VarBuilder\)", r"impl Module for ResBlk"]),
+        ("deform_conv.rs", "deform_conv.rs:17-222", [r"pub struct DeformableConv2d", r"pub fn new\(in_channels: usize, out_channels: usize, kernel_size: usize, stride: usize, padding: usize, vb: VarBuilder\)",
+                                                     r"pub fn forward\(&self, x: &Tensor\) -> Result<Tensor>", r"impl Module for DeformableConv2d"]),
+        ("swin.rs", "swin.rs:14-88", [r"pub struct SwinConfig", r"pub fn swin_t\(\) -> Self", r"pub fn swin_s\(\) -> Self", r"pub fn swin_b\(\) -> Self", r"pub fn swin_l\(\) -> Self",
+                                      r"pub fn stage_channels\(&self\) -> Vec<usize>"] +
+                                     [rf"pub {f}:" for f in ("embed_dim", "depths", "num_heads", "window_size", "mlp_ratio", "patch_size", "in_channels", "drop_path_rate")]),
+        ("swin.rs", "swin.rs:659-715", [r"pub struct PatchEmbed", r"pub fn new\(patch_size: usize, in_channels: usize, embed_dim: usize, norm: bool, vb: VarBuilder\)", r"pub fn forward\(&self, x: &Tensor\) -> Result<Tensor>"]),
+        ("swin.rs", "swin.rs:718-797", [r"pub struct SwinTransformer", r"pub fn new\(config: SwinConfig, vb: VarBuilder\) -> Result<Self>", r"pub fn forward\(&self, x: &Tensor\) -> Result<Vec<Tensor>>"]),
+    ]
+    n_items = 0
+    for fn, where, pats in PUB:
+        for pat in pats:
+            n_items += 1
+            if not re.search(pat, src[fn], re.S):
+                errs.append(f"rust_shim/src/{fn}: public item of the reference ({where}) not found: /{pat}/")
+    # compute-mode names the shim accepts from the environment must be modes the PRODUCT library builds (bf16_operands is diag-only)
+    comp = re.search(r"fn compute_from_env\(\) -> i32 \{(.*?)\n\}", src["birefnet.rs"], re.S).group(1)
+    api = open(os.path.join(ROOT, "candle_birefnet_amd", "csrc", "brn_api.cpp")).read()
+    for name, const in re.findall(r'Ok\("(\w+)"\) => ffi::(BRN_\w+)', comp):
+        if const == "BRN_BF16_OPERANDS" or f"dt == {const}" not in api:
+            errs.append(f"compute_from_env maps '{name}' to {const}, which brn_model_create of the product library refuses")
+    for fn in ("birefnet.rs",):
+        if "bf16_operands" in src[fn]:
+            errs.append(f"rust_shim/src/{fn} still mentions the diag-only mode bf16_operands")
+    if "bf16_operands" in open(os.path.join(ROOT, "INTEGRATION.md")).read():
+        errs.append("INTEGRATION.md still advertises BIREFNET_HIP_COMPUTE=bf16_operands")
     for e in errs:
         print("MISMATCH:", e)
+    print(f"{n_items} public items of the reference checked in rust_shim/src")
     print(f"{len(hf)} header entry points, {len(rf)} in hip_ffi.rs, {len(errs)} problem(s)")
     return 1 if errs else 0
 
