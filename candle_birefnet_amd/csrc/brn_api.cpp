@@ -777,6 +777,46 @@ brn_status brn_linear_forward(const float* x, int M, int K, const float* w, cons
     });
 }
 
+brn_status brn_linear_residual_layer_norm_forward(const float* x, int M, int K, const float* w, const float* bias, int N, const float* residual,
+                                                  const float* gamma, const float* beta, float eps, float* x_out, float* y_out, brn_mem loc,
+                                                  int device, void* stream) {
+    return guarded([&] {
+        if (!x || !w || !residual || !gamma || !beta || !x_out || !y_out || M < 1 || N < 1 || K < 1) fail(BRN_ERR_INVALID_ARG, "bad argument");
+        if (N % 4 || N > 3072) fail(BRN_ERR_INVALID_ARG, "layer_norm width %d unsupported (multiple of 4, <= 3072)", N);
+        if (eps != 1e-5f) fail(BRN_ERR_INVALID_ARG, "the fused projection + LayerNorm kernels are built for eps = 1e-5 (swin.rs:333-335)");
+        ensure_device(device);
+        DeviceOwner own;
+        OpPlanes op_planes;
+        GemmW g = make_linear(own, w, bias, N, K);
+        if (g_op_planes == BUILD_BF16 && K == 192 && N == 192) attach_dense_frags(own, g, w);
+        LNW ln; ln.C = N; ln.g = own.upload(gamma, N); ln.b = own.upload(beta, N);
+        Staging st(stream, loc);
+        const float* dx = st.in(x, (size_t)M * K);
+        const float* dr = st.in(residual, (size_t)M * N);
+        float* dxo = st.out(x_out, (size_t)M * N);
+        float* dyo = st.out(y_out, (size_t)M * N);
+        const bool bf = g_op_planes == BUILD_BF16;
+        with_arena((hipStream_t)stream, [&](Ctx& c) {
+            const float* a = dx;
+            float* yb = dyo;
+            if (bf) {                                                   // x rounded to bf16 at the edge, y produced as a bf16 matrix and widened
+                float* xb = c.arena->alloc_bytes((size_t)M * K * 2);
+                yb = c.arena->alloc_bytes((size_t)M * N * 2);
+                if (!c.dry) BRN_HIP(launch_f32_to_bf16(dx, (size_t)M * K, xb, c.stream));
+                a = xb;
+            }
+            // the residual stream is updated in place inside the model: here x_out starts as a copy of the residual
+            if (!c.dry) BRN_HIP(hipMemcpyAsync(dxo, dr, (size_t)M * N * sizeof(float), hipMemcpyDeviceToDevice, c.stream));
+            if (!linear_residual_ln(c, g, a, M, K, dxo, ln, yb, N)) {
+                run_gemm(c, g, a, M, K, dxo, N, 0, dxo, N, 0, nullptr, 0, 0, 0, bf ? 1 : 0, bf ? 1 : 0);
+                run_layernorm(c, ln, dxo, M, N, yb, N, 0, 0, bf ? 1 : 0);
+            }
+            if (bf && !c.dry) BRN_HIP(launch_bf16_to_f32(yb, (size_t)M * N, dyo, c.stream));
+        }, bf);
+        st.finish();
+    });
+}
+
 brn_status brn_layer_norm_forward(const float* x, int rows, int C, const float* gamma, const float* beta, float eps, float* y,
                                   brn_mem loc, int device, void* stream) {
     return guarded([&] {

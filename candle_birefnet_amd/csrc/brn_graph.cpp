@@ -304,16 +304,36 @@ void swin_stage_dims(int H, int W, int patch, int hs[4], int ws[4]) {
     }
 }
 
-// proj + residual + the block's second LayerNorm in one launch (gemm_wstat_ln_bf16_kernel: compute mode BRN_BF16, C = 192, M >= 32768);
+// proj + residual + the block's second LayerNorm in one launch (compute mode BRN_BF16: gemm_wstat_ln_bf16_kernel for C = 192, M >= 32768;
+// gemm_rowln_bf16_kernel for C = 768 / 384, M >= 4096);
 // false = not applicable, nothing enqueued (no workspace is involved either way, so a dry run and a real run agree trivially)
+bool linear_residual_ln(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* x, const LNW& ln, float* y, int ldy);
 static bool run_gemm_ln(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* x, const LNW& ln, float* y, int ldy) {
+    return linear_residual_ln(c, w, A, M, lda, x, ln, y, ldy);
+}
+bool linear_residual_ln(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* x, const LNW& ln, float* y, int ldy) {
     static const bool off = getenv("BRN_WSTAT_LN") && atoi(getenv("BRN_WSTAT_LN")) == 0;
-    if (!c.bf16 || off || !w.wf || w.mode != GEMM_DENSE || ln.C != w.N || !ln.g || !ln.b) return false;
+    static const int rowln_mask = getenv("BRN_ROWLN") ? atoi(getenv("BRN_ROWLN")) : 1;     // bit 0: N = 768 (stage 2), bit 1: N = 384 (stage 1)
+    if (!c.bf16 || w.mode != GEMM_DENSE || ln.C != w.N || !ln.g || !ln.b) return false;
     GemmParams p{};
     p.A = A; p.C = x; p.M = M; p.N = w.N; p.K = w.K; p.mode = GEMM_DENSE; p.lda = lda;
     p.bias = w.bias; p.scale = w.scale; p.shift = w.shift; p.act = w.act;
     p.R = x; p.ldr = w.N; p.ldc = w.N; p.c_f32 = 1; p.r_f32 = 1;
-    p.Wp = w.wf; p.planes = 1;
+    p.planes = 1;
+    // wide stages: the workgroup owns 64 whole rows and W streams through LDS (gemm_rowln_bf16_kernel)
+    if (w.wb && (rowln_mask & (w.N == 768 ? 1 : w.N == 384 ? 2 : 0))) {
+        p.Wp = w.wb; p.wp_rows = w.wb_rows; p.wp_ld = w.wb_ld;
+        if (gemm_rowln_eligible(p)) {
+            if (c.dry) return true;
+            const double flop = 2.0 * M * (double)w.N * w.K;
+            const double bytes = 2.0 * ((double)M * w.K + (double)w.N * w.K) + (4.0 + 4.0 + 2.0) * (double)M * w.N;
+            Bracket b(c, FAM_GEMM_DENSE, flop, bytes, M, w.N, w.K);
+            BRN_LAUNCH(launch_gemm_rowln(p, ln.g, ln.b, 1e-5f, y, ldy, c.stream));
+            return true;
+        }
+    }
+    if (off || !w.wf) return false;
+    p.Wp = w.wf; p.wp_rows = 0; p.wp_ld = 0;
     if (!gemm_wstat_ln_eligible(p)) return false;
     if (c.dry) return true;
     const double flop = 2.0 * M * (double)w.N * w.K;
@@ -499,18 +519,18 @@ void swin_forward(Ctx& c, const SwinW& w, const float* img, int B, int H, int W,
 }
 
 // ---- BasicDecBlk (decoder.rs:126-141) with ASPPDeformable (aspp.rs:303-333) ------------------------------------------------
-void decblk_forward(Ctx& c, const DecBlkW& w, const Map& in, const Map& out, int deform_mode) {
+void decblk_forward(Ctx& c, const DecBlkW& w, const Map& in, const Map& out, int deform_mode, int out_f32) {
     const size_t mk = c.arena->mark();
     Map t = new_map(c, in.B, in.H, in.W, 64);
     run_conv(c, w.conv_in, in, t);                                   // conv_in + bn_in + relu
     if (!w.has_aspp) {                                               // dec_att is None (decoder.rs:131-135)
-        run_conv(c, w.conv_out, t, out);
+        run_conv(c, w.conv_out, t, out, nullptr, 0, 0, out_f32);
         c.arena->release(mk);
         return;
     }
     Map u = new_map(c, in.B, in.H, in.W, 64);
     aspp_forward(c, w.aspp, t, u, deform_mode);
-    run_conv(c, w.conv_out, u, out);                                 // conv_out + bn_out (no ReLU)
+    run_conv(c, w.conv_out, u, out, nullptr, 0, 0, out_f32);         // conv_out + bn_out (no ReLU)
     c.arena->release(mk);
 }
 
@@ -657,15 +677,21 @@ void decoder_forward(Ctx& c, const Model& m, const float* img, int B, int H, int
     // stage 1 (birefnet.rs:362-369)
     run_resize(c, p2, d1.window(0, 384), lat_done);
     if (!lat_done) run_gemm(c, d.lat[2], c.at(x1.p, x1.coff), B * h1 * w1, x1.ld, d1.p, d1.ld, 0, d1.p, d1.ld, 0);
-    Map p1 = new_map(c, B, h1, w1, 192);
-    decblk_forward(c, d.dec[3], d1, p1, dm);
+    // p1 is the last map of the chain and feeds a 192-term dot product per pixel (the head): in compute mode BRN_BF16 it is kept fp32
+    // (BRN_P1_F32=0: bf16 like every other map) — its rounding is the one error of the decoder that nothing downstream averages
+    static const bool p1_f32_env = !(getenv("BRN_P1_F32") && atoi(getenv("BRN_P1_F32")) == 0);
+    const bool p1_f32 = c.bf16 && p1_f32_env;
+    Map p1;
+    if (p1_f32) { p1.B = B; p1.H = h1; p1.W = w1; p1.C = 192; p1.ld = 192; p1.coff = 0; p1.p = c.arena->alloc((size_t)B * h1 * w1 * 192); }
+    else p1 = new_map(c, B, h1, w1, 192);
+    decblk_forward(c, d.dec[3], d1, p1, dm, p1_f32 ? 1 : 0);
     // head (birefnet.rs:372-375): q = <p1, w[0:192]> at 1/4 res; t = the whole ipt_blk1 branch (conv1 -> conv_out -> its
     // slice of conv_out1) as one composed 5x5 stencil on the image (brn_weights.cpp): no 64-channel 1024^2 map exists
     float* q = c.arena->alloc((size_t)B * h1 * w1);
     float* tl = c.arena->alloc((size_t)B * H * W);
     if (!c.dry) {
         Bracket b(c, FAM_ELEMENTWISE, 2.0 * B * H * (double)W * 75, 4.0 * B * H * (double)W * 5);
-        BRN_LAUNCH(launch_pixel_dot(p1.p, B * h1 * w1, 192, p1.ld, p1.coff, d.out_w, 0.f, q, c.stream, c.bf16));
+        BRN_LAUNCH(launch_pixel_dot(p1.p, B * h1 * w1, 192, p1.ld, p1.coff, d.out_w, 0.f, q, c.stream, c.bf16 && !p1_f32));
         BRN_LAUNCH(launch_head_stencil5x5(img, B, H, W, d.head_k, d.head_b, tl, c.stream));
         BRN_LAUNCH(launch_final_head(q, B, h1, w1, tl, d.out_b, H, W, apply_sigmoid, out, c.stream));
     }

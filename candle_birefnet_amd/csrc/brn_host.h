@@ -245,6 +245,9 @@ void attach_dense_frags(DeviceOwner& own, GemmW& g, const float* w);
 void run_conv_nchw(Ctx& c, const GemmW& w, const float* x_nchw, int B, int Hin, int Win, const Map& out, bool pad_to_stride = false);
 void run_layernorm(Ctx& c, const LNW& ln, const float* x, int rows, int ldx, float* y, int ldy, int y_coff, int y_planes = 0, int y_bf16 = 0);
 void run_resize(Ctx& c, const Map& in, const Map& out, bool accumulate = false);
+// compute mode BRN_BF16: x = A W^T + bias + x (fp32, in place) and y = LayerNorm(x) as a bf16 matrix in ONE launch where a row-owning
+// kernel covers the shape (N = 192: gemm_wstat_ln_bf16_kernel; N = 768 / 384: gemm_rowln_bf16_kernel); false = nothing enqueued
+bool linear_residual_ln(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* x, const LNW& ln, float* y, int ldy);
 
 // SwinTransformer::forward (swin.rs:768-797): outs[i] are destination windows (stage outputs after norm_i)
 void swin_forward(Ctx& c, const SwinW& w, const float* img_nchw, int B, int H, int W, const Map outs[4]);
@@ -255,7 +258,7 @@ void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int 
 // the attention half of one block (swin.rs:356-403), x is the norm1 output, y = proj(attn) (no residual) or += residual
 void swin_attention(Ctx& c, const SwinBlockW& blk, const float* xn, int B, int H, int W, int C, int shift,
                     float* y, const float* residual, int window = 12);
-void decblk_forward(Ctx& c, const DecBlkW& w, const Map& in, const Map& out, int deform_mode);
+void decblk_forward(Ctx& c, const DecBlkW& w, const Map& in, const Map& out, int deform_mode, int out_f32 = 0 /* BRN_BF16: `out` is an fp32 map */);
 // ASPPDeformable::forward (aspp.rs:303-333) on a 64-channel map t -> 64-channel map u (both whole maps: ld == C == 64)
 void aspp_forward(Ctx& c, const ASPPW& a, const Map& t, const Map& u, int deform_mode);
 // the decoder's concat maps (birefnet.rs:332,347,362) — allocated by the caller when the image-patch convolutions that fill their

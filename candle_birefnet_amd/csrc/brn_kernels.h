@@ -77,6 +77,9 @@ hipError_t launch_patch_embed_ln(const float* img, int B, int H, int W, const fl
                                  const float* beta, float eps, float* x, int ldx, hipStream_t s, const float* gamma1 = nullptr,
                                  const float* beta1 = nullptr, void* xn_bf16 = nullptr, int ldxn = 0);   // (gamma1 / beta1 / xn: also LayerNorm(x) gamma1 + beta1 as a bf16 matrix)
 bool gemm_wstat_ln_eligible(const GemmParams& p);
+// the same fusion for N = 768 / 384 (any K % 32 == 0): gemm_rowln_bf16_kernel, a workgroup owns 64 whole rows, Wp = the plain [wp_rows][wp_ld] bf16 matrix
+bool gemm_rowln_eligible(const GemmParams& p);
+hipError_t launch_gemm_rowln(const GemmParams& p, const float* gamma, const float* beta, float eps, void* y_bf16, int ldy, hipStream_t s);
 hipError_t launch_gemm_wstat_ln(const GemmParams& p, const float* gamma, const float* beta, float eps, void* y_bf16, int ldy, hipStream_t s);
 
 // bf16-storage mode, modulated deformable conv (kernels/deform_bf16.hip): A = bf16 channels-last map, om = fp32 offsets | modulator,
@@ -155,6 +158,7 @@ hipError_t launch_pixel_dot(const float* x, int npix, int C, int ldx, int x_coff
                             float* y, hipStream_t s, int bf16 = 0);
 // contiguous fp32 -> bf16 (round to nearest even)
 hipError_t launch_f32_to_bf16(const float* x, size_t n, float* y_bf16, hipStream_t s);
+hipError_t launch_bf16_to_f32(const float* x_bf16, size_t n, float* y, hipStream_t s);
 // final head (birefnet.rs:372-375 with conv_out1 commuted through the bilinear upsample):
 // out[b][oy][ox] = bilinear(q [B,h,w] -> H,W) + t[b][oy][ox] (+bias); optional sigmoid
 hipError_t launch_final_head(const float* q, int B, int h, int w, const float* t, float bias, int H, int W,

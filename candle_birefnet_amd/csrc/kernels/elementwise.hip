@@ -391,6 +391,15 @@ hipError_t launch_f32_to_bf16(const float* x, size_t n, float* y_bf16, hipStream
     return hipGetLastError();
 }
 
+// bf16 -> fp32 of a contiguous buffer (op-level entry points that hand a bf16 result back across the fp32 boundary)
+__global__ void bf16_to_f32_kernel(const __bf16* __restrict__ x, size_t n, float* __restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = (float)x[i];
+}
+hipError_t launch_bf16_to_f32(const float* x_bf16, size_t n, float* y, hipStream_t s) {
+    hipLaunchKernelGGL(bf16_to_f32_kernel, grid1d(n, 256), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x_bf16), n, y);
+    return hipGetLastError();
+}
+
 __global__ void sigmoid_kernel(const float* __restrict__ x, size_t n, float* __restrict__ y) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         y[i] = 1.0f / (1.0f + expf(-x[i]));

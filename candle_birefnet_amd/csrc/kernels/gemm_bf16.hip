@@ -962,6 +962,172 @@ __global__ void __launch_bounds__(256, 2) gemm_wstat_ln_bf16_kernel(const GemmPa
         }
     }
 }
+// =====================================================================================================================
+// gemm_rowln_bf16_kernel<NC> (round 4) — the row-owning projection for the WIDE stages (NC = 768: stage 2, 18 of the 24 blocks; NC = 384:
+// stage 1): x = A W^T + bias + x on the fp32 residual stream (in place) AND y = LayerNorm(x) gamma + beta as the bf16 operand of the next
+// GEMM, in one launch (swin.rs:310,406,407) — the stand-alone LayerNorm launch and its fp32 re-read of x are gone.
+// A workgroup of 8 waves owns 64 WHOLE rows (64 x NC fp32 accumulators = 96 / 48 VGPRs per lane; wave w = columns [w NC/8, (w+1) NC/8)),
+// so the row statistics are local.  W does not fit anything but L2, so it streams through LDS: K step 32 (64-byte tile rows, four per
+// 256-byte bank row, 16-byte chunks XOR-ed with the bank row as in gemm_bf16_kernel<BBK = 32>), three ring slots of (64 + NC) x 64 B, the
+// pieces of K step t + 2 issued right after the barrier of step t (counted vmcnt; waves 0-3 carry the A pieces).  Per 64 rows the
+// workgroup takes in the whole W (1.18 MB at NC = 768): the K loop is bound by the CU's L2 -> LDS intake, not by the matrix pipe, and the
+// launch as a whole by HBM (A once, x read + written once, y once) — which is the point: 378 MB per stage-2 launch instead of the 504 MB of
+// projection + LayerNorm.  Epilogue: the C tile leaves through the ring as fp32 in two 32-row halves (16-byte chunks XOR-ed with the row),
+// comes back with 16 lanes per row (whole 256-byte segments), + residual, store x, two-pass mean / biased variance (the arithmetic of
+// layernorm_kernel), store y.  The next tile's first K step is already in flight (slot 2) during the epilogue.
+// =====================================================================================================================
+template <int NC>
+__global__ void __launch_bounds__(512) gemm_rowln_bf16_kernel(const GemmParams p, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float eps, __bf16* __restrict__ Y, const int ldy) {
+    constexpr int RBM = 64, RBK = 32, ROWB = RBK * 2;                    // 64-byte tile rows
+    constexpr int WCOL = NC / 8;                                         // columns per wave: 96 / 48
+    constexpr int FN = WCOL / 16, FM = RBM / 16;                         // 16 x 16 blocks of a wave tile
+    constexpr int A_BYTES = RBM * ROWB, SLOT = (RBM + NC) * ROWB;        // 4 KB + 48 / 24 KB
+    constexpr int LW = NC / 16 / 8;                                      // W pieces (1 KiB = 16 tile rows) per wave and K step: 6 / 3
+    constexpr int HALF_BYTES = 32 * NC * 4;                              // a 32-row half of the fp32 C tile
+    constexpr int CH_ROW = NC / 4, CPL = CH_ROW / 16;                    // 16-byte chunks per C row, chunks per lane in the read-back (16 lanes per row)
+    static_assert(3 * SLOT <= 160 * 1024 && HALF_BYTES <= 2 * SLOT - 0 && NC % 128 == 0, "ring / epilogue geometry");
+    __shared__ __attribute__((aligned(1024))) char smem[3 * SLOT];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = (p.M + RBM - 1) / RBM;
+    const int xcd = blockIdx.x & 7, wk = blockIdx.x >> 3, nw = (int)gridDim.x >> 3;
+    const int t_lo = (int)((long)T * xcd / 8), t_hi = (int)((long)T * (xcd + 1) / 8);
+    const int nk = p.K / RBK;
+    const __bf16* Ab = reinterpret_cast<const __bf16*>(p.A);
+    const __bf16* Wb = reinterpret_cast<const __bf16*>(p.Wp);
+
+    // ---- LDS-DMA: instruction ii fills bank rows 4 ii .. 4 ii + 3 (16 tile rows); lane -> (tile row, k chunk) through the swizzle ----
+    const int pr_l = lane >> 4;
+    // (bank row pr = 4 ii + pr_l, key pr & 3 = pr_l: the lane's logical slot and hence its (row in the 16-row piece, chunk) are the same for every piece)
+    const int qs = (lane & 15) ^ pr_l;
+    const int row16 = 4 * pr_l + (qs >> 2);                              // row within a 16-row piece
+    const unsigned kch_b = (unsigned)((qs & 3) * 16);                    // byte offset of the lane's k chunk within the 64-byte K step
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Wb), 0, 0x7fffffff, 0x00020000);
+    unsigned w_voff[LW];
+#pragma unroll
+    for (int j = 0; j < LW; ++j) w_voff[j] = (unsigned)((16 * (wave * LW + j) + row16) * p.wp_ld * 2) + kch_b;
+    auto issue = [&](int m0, int kt, int slot) {                         // K step kt of the row tile at m0 into ring slot `slot`
+        char* sb = smem + slot * SLOT;
+        if (wave < 4) {
+            const int r = 16 * wave + row16;
+            const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Ab + (long)m0 * p.lda + p.a_coff), 0, 0x7fffffff, 0x00020000);
+            const unsigned vo = (unsigned)((min(m0 + r, p.M - 1) - m0) * p.lda * 2) + kch_b;     // rows >= M re-read row M - 1 (never stored)
+            blds16(a_rsrc, vo, kt * ROWB, sb + wave * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < LW; ++j) blds16(w_rsrc, w_voff[j], kt * ROWB, sb + A_BYTES + (wave * LW + j) * 1024);
+    };
+    // fragment offsets within a slot: 16x16x32: lane reads row (lane & 15) of a 16-row block (4 bank rows), chunk lane >> 4 (all of a K step)
+    const int f_off = ((lane & 15) >> 2) * 256 + (((((lane & 15) & 3) << 2) | (lane >> 4)) ^ (((lane & 15) >> 2) & 3)) * 16;
+
+    int t = t_lo + wk;
+    if (t < t_hi) issue(t * RBM, 0, 2);                                  // K step kt lives in slot (kt + 2) % 3
+    for (; t < t_hi; t += nw) {
+        const int m0 = t * RBM;
+        f32x4_b acc[FM][FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = zero4b();
+        if (nk > 1) issue(m0, 1, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            // this wave's pieces of step kt have landed when at most those of step kt + 1 are outstanding
+            if (kt + 1 < nk) { if (wave < 4) wait_vmcnt<LW + 1>(); else wait_vmcnt<LW>(); }
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();                                // everybody's pieces landed; everybody is done reading step kt - 1
+            if (kt + 2 < nk) issue(m0, kt + 2, (kt + 4) % 3);            // into the slot step kt - 1 just left
+            const char* sb = smem + ((kt + 2) % 3) * SLOT;
+            bf16x8 af[FM], bfr[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sb + i * 1024 + f_off);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + A_BYTES + (wave * FN + j) * 1024 + f_off);
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int i = 0; i < FM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                    // every fragment read of the tile is done: the ring is free
+        const bool more = t + nw < t_hi;
+        if (more) issue((t + nw) * RBM, 0, 2);                           // the next tile's first K step flies during the epilogue (slot 2 is not touched by it)
+        // ---- epilogue: two 32-row halves through smem[0, HALF_BYTES) ----
+        const int er = tid >> 4, ec = tid & 15;                          // read-back: row of the half, first chunk (then + 16 k)
+        float* Cf = reinterpret_cast<float*>(p.C);
+        const float* Rf = reinterpret_cast<const float*>(p.R);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int m = m0 + half * 32 + er, mc = min(m, p.M - 1);
+            f32x4_b rr[CPL];
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) rr[k] = *reinterpret_cast<const f32x4_b*>(Rf + (long)mc * p.ldr + p.r_coff + (ec + 16 * k) * 4);
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = 2 * half + ii, row = 16 * ii + (lane & 15);
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int col = wave * WCOL + 16 * j + 4 * (lane >> 4);
+                    f32x4_b bias4 = p.bias ? *reinterpret_cast<const f32x4_b*>(p.bias + col) : zero4b();
+                    const int ch = col >> 2;
+                    *reinterpret_cast<f32x4_b*>(smem + row * (NC * 4) + (((ch & ~15) | ((ch ^ row) & 15)) << 4)) = acc[i][j] + bias4;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            f32x4_b xv[CPL];
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                const int ch = ec + 16 * k;
+                xv[k] = *reinterpret_cast<const f32x4_b*>(smem + er * (NC * 4) + (((ch & ~15) | ((ch ^ er) & 15)) << 4)) + rr[k];
+                sum += (xv[k][0] + xv[k][1]) + (xv[k][2] + xv[k][3]);
+            }
+            if (m < p.M) {
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) *reinterpret_cast<f32x4_b*>(Cf + (long)m * p.ldc + p.c_coff + (ec + 16 * k) * 4) = xv[k];
+            }
+            sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8);
+            const float mean = sum / (float)NC;
+            float sq = 0.f;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                xv[k] = xv[k] - mean;
+                sq += (xv[k][0] * xv[k][0] + xv[k][1] * xv[k][1]) + (xv[k][2] * xv[k][2] + xv[k][3] * xv[k][3]);
+            }
+            sq += __shfl_xor(sq, 1); sq += __shfl_xor(sq, 2); sq += __shfl_xor(sq, 4); sq += __shfl_xor(sq, 8);
+            const float rstd = 1.0f / sqrtf(sq / (float)NC + eps);
+            if (m < p.M) {
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) {
+                    const int c0 = (ec + 16 * k) * 4;
+                    const f32x4_b gm = *reinterpret_cast<const f32x4_b*>(gamma + c0), bt = *reinterpret_cast<const f32x4_b*>(beta + c0);
+                    const f32x4_b o = xv[k] * rstd * gm + bt;
+                    const u32x2_b ob = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+                    *reinterpret_cast<u32x2_b*>(Y + (long)m * ldy + c0) = ob;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                               // the half is free again (second half; after it: the K loop's slots 0 / 1)
+        }
+    }
+}
+bool gemm_rowln_eligible(const GemmParams& p) {
+    return p.mode == GEMM_DENSE && p.Wp && (p.N == 768 || p.N == 384) && p.K >= 64 && (p.K % 32) == 0 && p.c_f32 && p.R && p.r_f32 && !p.scale && !p.bbias &&
+           p.act == ACT_NONE && ((p.lda | p.a_coff) & 7) == 0 && ((p.ldc | p.c_coff | p.ldr | p.r_coff) & 3) == 0 && p.M >= 8192 && p.wp_rows >= p.N &&
+           p.wp_ld >= p.K && (p.wp_ld & 7) == 0 && (double)p.wp_ld * 2.0 * p.N < 2147483648.0 && (double)p.lda * 2.0 * 64 < 2147483648.0;
+}
+hipError_t launch_gemm_rowln(const GemmParams& p, const float* gamma, const float* beta, float eps, void* y_bf16, int ldy, hipStream_t s) {
+    if (!gemm_rowln_eligible(p) || !gamma || !beta || !y_bf16 || (ldy & 3)) return hipErrorInvalidValue;
+    const int tiles = (p.M + 63) / 64;
+    int g = launch_cus();
+    if (g > tiles) g = (tiles + 7) / 8 * 8;
+    dim3 grid(g), block(512);
+    if (p.N == 768) hipLaunchKernelGGL(gemm_rowln_bf16_kernel<768>, grid, block, 0, s, p, gamma, beta, eps, reinterpret_cast<__bf16*>(y_bf16), ldy);
+    else hipLaunchKernelGGL(gemm_rowln_bf16_kernel<384>, grid, block, 0, s, p, gamma, beta, eps, reinterpret_cast<__bf16*>(y_bf16), ldy);
+    return hipGetLastError();
+}
+
 bool gemm_wstat_ln_eligible(const GemmParams& p) {
     return p.mode == GEMM_DENSE && p.Wp && p.K == 192 && p.N == 192 && p.c_f32 && p.R && p.r_f32 && !p.scale && !p.bbias && p.act == ACT_NONE &&
            ((p.lda | p.a_coff) & 7) == 0 && ((p.ldc | p.c_coff | p.ldr | p.r_coff) & 3) == 0 && p.M >= 32768 && (long)p.lda * 2 * 64 < 0x7fffffffL;

@@ -129,3 +129,19 @@ def decblk(x, tensors, out_channels, mode="reference_cpu", prefix="", use_aspp=T
                                            T.device_of(keep, device), T.stream_of(keep)))
     del keep_w
     return y
+
+
+def linear_residual_layer_norm(x, w, bias, residual, gamma, beta, eps=1e-5, device=0):
+    """x_out = x W^T + bias + residual; y_out = LayerNorm(x_out) gamma + beta — swin.rs:310 + :406 + :407 (and :106-107 + the next block's
+    norm1) as one call; returns (x_out, y_out), both [M,N]."""
+    M, K = (int(v) for v in x.shape)
+    N = int(w.shape[0])
+    px, loc, keep, _ = T.as_arg(x)
+    pr, rloc, rkeep, _ = T.as_arg(residual, (M, N))
+    if rloc != loc:
+        raise ValueError("x and residual must live on the same side")
+    (pw, kw), (pb, kb), (pg, kg), (pbt, kbt) = T.host_ptr(w), T.host_ptr(bias), T.host_ptr(gamma), T.host_ptr(beta)
+    xo, yo = T.alloc_like(keep, (M, N)), T.alloc_like(keep, (M, N))
+    _ffi.check(_ffi.lib.brn_linear_residual_layer_norm_forward(px, M, K, pw, pb, N, pr, pg, pbt, float(eps), T.ptr_of(xo), T.ptr_of(yo), loc,
+                                                               T.device_of(keep, device), T.stream_of(keep)))
+    return xo, yo

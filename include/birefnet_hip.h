@@ -189,6 +189,15 @@ brn_status brn_set_op_compute(int dtype);
 brn_status brn_linear_forward(const float* x, int M, int K, const float* w, const float* bias, int N,
                               int act, const float* residual, float* y, brn_mem loc, int device_ordinal,
                               void* stream);
+/* The attention half's tail of a Swin block as the reference chains it (swin.rs:310 proj, :406 shortcut + attn, :407 norm2 — and the
+ * same shape at the end of the MLP, :106-107 + the next block's norm1): x_out = x W^T + bias + residual, y_out = LayerNorm(x_out) gamma +
+ * beta (eps inside the sqrt, biased variance).  x [M,K], w [N,K], residual / x_out / y_out [M,N], all fp32 at this boundary.  In compute
+ * mode bf16 (brn_set_op_compute) x is rounded to bf16 at the edge and the pair runs as ONE row-owning kernel where the shape allows (N = 192,
+ * 384, 768: gemm_wstat_ln_bf16_kernel / gemm_rowln_bf16_kernel; y_out is then a bf16-rounded matrix), otherwise as a GEMM and a LayerNorm launch. */
+brn_status brn_linear_residual_layer_norm_forward(const float* x, int M, int K, const float* w, const float* bias, int N,
+                                                  const float* residual, const float* gamma, const float* beta, float eps,
+                                                  float* x_out, float* y_out, brn_mem loc, int device_ordinal, void* stream);
+
 /* candle_nn::layer_norm(dim, eps) forward (swin.rs:333,335,486,680,754): rows of length C. */
 brn_status brn_layer_norm_forward(const float* x, int rows, int C, const float* gamma, const float* beta,
                                   float eps, float* y, brn_mem loc, int device_ordinal, void* stream);

@@ -99,6 +99,9 @@ extern "C" {
     pub fn brn_set_op_compute(dtype: c_int) -> c_int;
     pub fn brn_linear_forward(x: *const c_float, m: c_int, k: c_int, w: *const c_float, bias: *const c_float, n: c_int, act: c_int,
                               residual: *const c_float, y: *mut c_float, loc: c_int, device_ordinal: c_int, stream: *mut c_void) -> c_int;
+    pub fn brn_linear_residual_layer_norm_forward(x: *const c_float, m: c_int, k: c_int, w: *const c_float, bias: *const c_float, n: c_int,
+                                                  residual: *const c_float, gamma: *const c_float, beta: *const c_float, eps: c_float,
+                                                  x_out: *mut c_float, y_out: *mut c_float, loc: c_int, device_ordinal: c_int, stream: *mut c_void) -> c_int;
     pub fn brn_layer_norm_forward(x: *const c_float, rows: c_int, c: c_int, gamma: *const c_float, beta: *const c_float, eps: c_float,
                                   y: *mut c_float, loc: c_int, device_ordinal: c_int, stream: *mut c_void) -> c_int;
     pub fn brn_conv2d_forward(x: *const c_float, b: c_int, c: c_int, h: c_int, w: c_int, wgt: *const c_float, bias: *const c_float,

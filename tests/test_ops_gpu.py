@@ -1,5 +1,8 @@
 """Op-level parity on the GPU: every C-ABI op entry point against a CPU restatement of the candle op it replaces.
 Tolerances are fp32 reorder noise (the MFMA f32 path is an exact fmaf chain): 2e-5 relative to the output scale."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -533,3 +536,85 @@ def test_decblk_forward_bf16_mode(gpu):
         err = np.abs(np.asarray(y, np.float64) - ref).max()
         print(f"decblk bf16 {cin}->{cout} {mode}: max abs err {err:.2e}, |ref| max {np.abs(ref).max():.2f}")
         assert err <= 3e-2 * max(1.0, np.abs(ref).max())
+
+
+def test_deform_conv2d_bf16_kernel_versions_bit_equal(gpu, tmp_path):
+    """gemm_deform_bf16_v2_kernel (one lane per (pixel, tap) computes the sampling parameters for the wave, corners fetched two K steps
+    ahead; the default) against the round-3 kernel (BRN_DEFORM_V=1: every thread computes them itself): the same products in the same
+    order, so the same bits — every geometry of test_deform_conv2d_bf16_mode plus taps that do not fill the last block of four, three
+    K steps per tap, a tile that spans two images, tiny maps.  Child processes: the switch is read once per process."""
+    import subprocess
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import candle_birefnet_amd as cb\nfrom candle_birefnet_amd import ops\nfrom test_ops_gpu import rnd\n"
+        "outs = {}\n"
+        "cases = [(3, 1, 1, 128, 32, 64, 2), (1, 1, 0, 256, 8, 64, 2), (7, 1, 3, 256, 12, 64, 2), (3, 2, 1, 64, 16, 64, 2), (3, 1, 1, 256, 19, 128, 2),\n"
+        "         (1, 1, 0, 256, 40, 64, 1), (7, 1, 3, 32, 9, 64, 3), (5, 1, 2, 64, 11, 192, 1), (3, 1, 1, 256, 6, 64, 5), (7, 1, 3, 256, 33, 64, 1)]\n"
+        "for i, (k, stride, pad, O, H, C, B) in enumerate(cases):\n"
+        "    t = {'offset_conv.weight': rnd(2 * k * k, C, k, k, seed=1, std=1.5 * (C * k * k) ** -0.5), 'offset_conv.bias': rnd(2 * k * k, seed=2, std=0.3),\n"
+        "         'modulator_conv.weight': rnd(k * k, C, k, k, seed=3, std=(C * k * k) ** -0.5), 'modulator_conv.bias': rnd(k * k, seed=4, std=0.1),\n"
+        "         'regular_conv.weight': rnd(O, C, k, k, seed=5, std=(C * k * k) ** -0.5), 'regular_conv.bias': rnd(O, seed=6, std=0.1)}\n"
+        "    layer = cb.DeformableConv2d.new(C, O, k, stride, pad, cb.VarBuilder.from_tensors(t), mode='deformable')\n"
+        "    ops.set_compute('bf16')\n"
+        "    outs[str(i)] = np.asarray(layer.forward(rnd(B, C, H, H + (i % 3), seed=9)))\n"
+        "    ops.set_compute('f32')\n"
+        "np.savez(sys.argv[1], **outs)\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for v in ("1", "2"):
+        out = str(tmp_path / f"v{v}.npz")
+        pr = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, BRN_DEFORM_V=v), capture_output=True, text=True, timeout=600)
+        assert pr.returncode == 0, pr.stderr[-2000:]
+        res[v] = np.load(out)
+    assert sorted(res["1"].files) == sorted(res["2"].files) and len(res["1"].files) == 10
+    for k_ in res["1"].files:
+        assert np.isfinite(res["2"][k_]).all()
+        np.testing.assert_array_equal(res["1"][k_], res["2"][k_])
+
+
+@pytest.mark.parametrize("M,K,N", [(8192, 768, 768), (8192 + 37, 768, 768), (20480, 768, 768), (9000, 3072, 768), (16384, 384, 384), (8200, 1536, 384),
+                                   (33000, 192, 192), (4096, 768, 768), (8192, 768, 1536)])
+def test_linear_residual_layer_norm_bf16_mode(gpu, M, K, N):
+    """x = A W^T + b + x; y = LayerNorm(x) (swin.rs:310,406,407) in compute mode bf16: gemm_rowln_bf16_kernel for N = 768 / 384 (64 whole
+    rows per workgroup, W streamed through LDS; K = 768 projection, K = 3072 / 1536 = the fc2 shape, ragged last tile, tile counts below
+    and above one round of workgroups), gemm_wstat_ln_bf16_kernel for N = 192, GEMM + LayerNorm launches otherwise (M below the fused
+    kernel's threshold, N = 1536).  Exact-operand reference: A and W rounded to bf16, everything else fp64; x is an fp32 matrix
+    (accumulation noise), y a bf16-rounded one (one ulp + the LayerNorm arithmetic in fp32)."""
+    from candle_birefnet_amd import ops
+    a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, std=K ** -0.5), rnd(N, seed=3, std=0.1)
+    r = rnd(M, N, seed=4, std=2.0)
+    g, bt = (1.0 + rnd(N, seed=5, std=0.05)).astype(np.float32), rnd(N, seed=6, std=0.02)
+    ops.set_compute("bf16")
+    try:
+        xo, yo = ops.linear_residual_layer_norm(a, w, b, r, g, bt)
+        xo2, yo2 = ops.linear_residual_layer_norm(a, w, b, r, g, bt)
+    finally:
+        ops.set_compute("f32")
+    np.testing.assert_array_equal(xo, xo2); np.testing.assert_array_equal(yo, yo2)
+    xr = _bf16_round(a) @ _bf16_round(w).T + b.astype(np.float64) + r.astype(np.float64)
+    mu = xr.mean(-1, keepdims=True)
+    var = ((xr - mu) ** 2).mean(-1, keepdims=True)
+    yr = (xr - mu) / np.sqrt(var + 1e-5) * g.astype(np.float64) + bt.astype(np.float64)
+    ex = np.abs(np.asarray(xo, np.float64) - xr).max()
+    ey = np.abs(np.asarray(yo, np.float64) - yr)
+    print(f"linear+residual+LN bf16 M{M} K{K} N{N}: x max abs err {ex:.2e} (|x| max {np.abs(xr).max():.1f}), y max abs err {ey.max():.2e}")
+    assert ex <= 2e-5 * max(1.0, np.abs(xr).max())
+    assert (ey <= 2.0 ** -8 * np.abs(yr) + 1e-4).all()
+
+
+def test_linear_residual_layer_norm_fp32_modes(gpu):
+    """the same entry in the fp32-class modes (GEMM + LayerNorm launches) against fp64"""
+    from candle_birefnet_amd import ops
+    M, K, N = 1000, 384, 768
+    a, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, std=K ** -0.5), rnd(N, seed=3, std=0.1), rnd(M, N, seed=4)
+    g, bt = (1.0 + rnd(N, seed=5, std=0.05)).astype(np.float32), rnd(N, seed=6, std=0.02)
+    xr = a.astype(np.float64) @ w.astype(np.float64).T + b + r
+    mu = xr.mean(-1, keepdims=True)
+    yr = (xr - mu) / np.sqrt(((xr - mu) ** 2).mean(-1, keepdims=True) + 1e-5) * g + bt
+    for mode in ("f32", "f32_split3", "f32_split2"):
+        ops.set_compute(mode)
+        try:
+            xo, yo = ops.linear_residual_layer_norm(a, w, b, r, g, bt)
+        finally:
+            ops.set_compute("f32")
+        _close(xo, xr, tol=3e-5 if mode != "f32_split2" else 2e-4)
+        _close(yo, yr, tol=3e-5 if mode != "f32_split2" else 2e-4)
