@@ -104,9 +104,9 @@ _sig("brn_patch_merging_forward", C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_i
 _sig("brn_deform_conv2d_forward", C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int,
      C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp)
 
-_sig("brn_aspp_deformable_forward", C.c_int, _vp, C.c_size_t, C.c_char_p, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp)
+_sig("brn_aspp_deformable_forward", C.c_int, _vp, C.c_size_t, C.c_char_p, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp)
 
-_sig("brn_decblk_forward", C.c_int, _vp, C.c_size_t, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int,
+_sig("brn_decblk_forward", C.c_int, _vp, C.c_size_t, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int,
      C.c_int, _vp)
 
 _sig("brn_preprocess_image", C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp)

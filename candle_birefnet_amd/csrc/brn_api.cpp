@@ -954,41 +954,44 @@ brn_status brn_patch_merging_forward(const float* x, int B, int H, int W, int C,
     });
 }
 
-brn_status brn_aspp_deformable_forward(const brn_named_tensor* weights, size_t n, const char* prefix, int mode, const float* x, int B,
-                                       int H, int W, float* y, brn_mem loc, int device, void* stream) {
+brn_status brn_aspp_deformable_forward(const brn_named_tensor* weights, size_t n, const char* prefix, int in_channels, int out_channels, int mode,
+                                       const float* x, int B, int H, int W, float* y, brn_mem loc, int device, void* stream) {
     return guarded([&] {
-        if (!weights || !x || !y || B < 1 || H < 1 || W < 1) fail(BRN_ERR_INVALID_ARG, "bad argument");
+        if (!weights || !x || !y || B < 1 || H < 1 || W < 1 || in_channels < 1 || out_channels < 0) fail(BRN_ERR_INVALID_ARG, "bad argument");
         if (mode != BRN_DEFORM_REFERENCE_CPU && mode != BRN_DEFORM_DEFORMABLE) fail(BRN_ERR_INVALID_ARG, "unknown deform mode %d", mode);
         ensure_device(device);
         DeviceOwner own;
         OpPlanes op_planes;
         WeightTable wt(weights, n);
         ASPPW a;
-        build_aspp_weights(wt, prefix ? prefix : "", mode, own, a);
+        build_aspp_weights(wt, prefix ? prefix : "", mode, own, a, in_channels, out_channels);
         Staging st(stream, loc);
-        const float* dx = st.in(x, (size_t)B * 64 * H * W);
-        float* dy = st.out(y, (size_t)B * 64 * H * W);
+        const float* dx = st.in(x, (size_t)B * a.ic * H * W);
+        float* dy = st.out(y, (size_t)B * a.oc * H * W);
         with_arena((hipStream_t)stream, [&](Ctx& c) {
-            Map T = new_map(c, B, H, W, 64), U = new_map(c, B, H, W, 64);
-            if (!c.dry) BRN_HIP(launch_nchw_to_nhwc(dx, B, 64, H, W, T.p, T.ld, 0, c.stream, c.bf16));
+            Map T = new_map(c, B, H, W, a.icp), U = new_map(c, B, H, W, a.oc);
+            if (!c.dry) {
+                if (a.icp != a.ic) BRN_HIP(hipMemsetAsync(T.p, 0, (size_t)B * H * W * a.icp * c.esz(), c.stream));   // the pad channels
+                BRN_HIP(launch_nchw_to_nhwc(dx, B, a.ic, H, W, T.p, T.ld, 0, c.stream, c.bf16));
+            }
             aspp_forward(c, a, T, U, mode);
-            if (!c.dry) BRN_HIP(launch_nhwc_to_nchw(U.p, B, 64, H, W, U.ld, 0, dy, c.stream, c.bf16));
+            if (!c.dry) BRN_HIP(launch_nhwc_to_nchw(U.p, B, a.oc, H, W, U.ld, 0, dy, c.stream, c.bf16));
         }, g_op_planes == BUILD_BF16);
         st.finish();
     });
 }
 
-brn_status brn_decblk_forward(const brn_named_tensor* weights, size_t n, const char* prefix, int cin, int cout, int use_aspp, int mode,
+brn_status brn_decblk_forward(const brn_named_tensor* weights, size_t n, const char* prefix, int cin, int cout, int inter, int use_aspp, int mode,
                               const float* x, int B, int H, int W, float* y, brn_mem loc, int device, void* stream) {
     return guarded([&] {
-        if (!weights || !x || !y || B < 1 || H < 1 || W < 1 || cin < 1 || cout < 1) fail(BRN_ERR_INVALID_ARG, "bad argument");
+        if (!weights || !x || !y || B < 1 || H < 1 || W < 1 || cin < 1 || cout < 1 || inter < 0) fail(BRN_ERR_INVALID_ARG, "bad argument");
         if (mode != BRN_DEFORM_REFERENCE_CPU && mode != BRN_DEFORM_DEFORMABLE) fail(BRN_ERR_INVALID_ARG, "unknown deform mode %d", mode);
         ensure_device(device);
         DeviceOwner own;
         OpPlanes op_planes;
         WeightTable wt(weights, n);
         DecBlkW blk;
-        build_decblk_weights(wt, prefix ? prefix : "", cin, cout, mode, own, blk, use_aspp != 0);
+        build_decblk_weights(wt, prefix ? prefix : "", cin, cout, mode, own, blk, use_aspp != 0, inter > 0 ? inter : 64);
         const int cinp = blk.conv_in.Cinp;                   // in_channels rounded up to the kernels' channel granule (zero weights there)
         const bool bf = g_op_planes == BUILD_BF16;
         Staging st(stream, loc);
@@ -1021,29 +1024,32 @@ brn_status brn_deform_conv2d_forward(const float* x, int B, int C, int H, int W,
             return;
         }
         if (mode != BRN_DEFORM_DEFORMABLE) fail(BRN_ERR_INVALID_ARG, "unknown deform mode %d", mode);
-        if (C % 32) fail(BRN_ERR_INVALID_ARG, "deformable mode needs in_channels %% 32 == 0 (got %d)", C);
         const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1, kk = k * k;
         ensure_device(device);
         DeviceOwner own;
         // compute mode BRN_BF16 at op level (brn_set_op_compute): bf16 map in / out as inside the model, offsets / modulator fp32, the
-        // gather on kernels/deform_bf16.hip where the shape allows; every other mode runs the fp32-MFMA gather kernel
-        const bool bf = g_op_planes == BUILD_BF16 && C >= 64 && (C % 64) == 0 && (O % 8) == 0;
+        // gather on kernels/deform_bf16.hip where the shape allows; every other mode runs the fp32-MFMA gather kernel.
+        // Any in_channels (deform_conv.rs:29-36): the channels-last map is padded with zero channels to the kernels' granule (32; 64 for
+        // the bf16 gather kernel), the weights with zero columns
+        const bool bf = g_op_planes == BUILD_BF16 && (O % 8) == 0;
+        const int Cp = (C + (bf ? 63 : 31)) / (bf ? 64 : 32) * (bf ? 64 : 32);
         struct Planes { Planes(int p) { set_build_planes(p); } ~Planes() { set_build_planes(0); } } planes_guard(bf ? BUILD_BF16 : 0);
         std::vector<float> w3((size_t)3 * kk * C * kk), b3((size_t)3 * kk);
         memcpy(w3.data(), offset_w, (size_t)2 * kk * C * kk * sizeof(float));
         memcpy(w3.data() + (size_t)2 * kk * C * kk, mod_w, (size_t)kk * C * kk * sizeof(float));
         memcpy(b3.data(), offset_b, (size_t)2 * kk * sizeof(float));
         memcpy(b3.data() + 2 * kk, mod_b, (size_t)kk * sizeof(float));
-        GemmW om = make_conv_nhwc(own, w3.data(), b3.data(), 3 * kk, C, C, k, k, stride, pad, 1);
+        GemmW om = make_conv_nhwc(own, w3.data(), b3.data(), 3 * kk, C, Cp, k, k, stride, pad, 1);
         om.mode = GEMM_CONV_NHWC;
-        GemmW reg = make_conv_nhwc(own, w, bias, O, C, C, k, k, stride, pad, 1);
+        GemmW reg = make_conv_nhwc(own, w, bias, O, C, Cp, k, k, stride, pad, 1);
         reg.mode = GEMM_DEFORM_NHWC;
         if (bf) attach_deform_frags(own, reg, w);
         Staging st(stream, loc);
         const float* dx = st.in(x, (size_t)B * C * H * W);
         float* dy = st.out(y, (size_t)B * O * Ho * Wo);
         with_arena((hipStream_t)stream, [&](Ctx& c) {
-            Map X = new_map(c, B, H, W, C), Y = new_map(c, B, Ho, Wo, O);
+            Map X = new_map(c, B, H, W, Cp), Y = new_map(c, B, Ho, Wo, O);
+            if (Cp != C && !c.dry) BRN_HIP(hipMemsetAsync(X.p, 0, (size_t)B * H * W * Cp * c.esz(), c.stream));
             const int ldom = (3 * kk + 3) / 4 * 4;
             Map OM; OM.B = B; OM.H = Ho; OM.W = Wo; OM.C = 3 * kk; OM.ld = ldom; OM.coff = 0;
             OM.p = c.arena->alloc((size_t)B * Ho * Wo * ldom);

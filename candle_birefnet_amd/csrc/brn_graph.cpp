@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <utility>
 
 namespace brn {
 
@@ -521,31 +522,40 @@ void swin_forward(Ctx& c, const SwinW& w, const float* img, int B, int H, int W,
 // ---- BasicDecBlk (decoder.rs:126-141) with ASPPDeformable (aspp.rs:303-333) ------------------------------------------------
 void decblk_forward(Ctx& c, const DecBlkW& w, const Map& in, const Map& out, int deform_mode, int out_f32) {
     const size_t mk = c.arena->mark();
-    Map t = new_map(c, in.B, in.H, in.W, 64);
-    run_conv(c, w.conv_in, in, t);                                   // conv_in + bn_in + relu
+    // the maps between the convs carry w.icp channels: inter_channels rounded up to the channel granule (64 -> 64 in the model); a conv
+    // writes its real output channels, so the pad channels of a fresh map are zeroed once
+    auto inter_map = [&](int chans, int padded) {
+        Map m_ = new_map(c, in.B, in.H, in.W, padded);
+        if (padded != chans && !c.dry) BRN_HIP(hipMemsetAsync(m_.p, 0, m_.pixels() * (size_t)padded * c.esz(), c.stream));
+        Map v = m_.window(0, chans);
+        return std::make_pair(m_, v);
+    };
+    auto [t, t_out] = inter_map(w.ic, w.icp);
+    run_conv(c, w.conv_in, in, t_out);                               // conv_in + bn_in + relu
     if (!w.has_aspp) {                                               // dec_att is None (decoder.rs:131-135)
         run_conv(c, w.conv_out, t, out, nullptr, 0, 0, out_f32);
         c.arena->release(mk);
         return;
     }
-    Map u = new_map(c, in.B, in.H, in.W, 64);
-    aspp_forward(c, w.aspp, t, u, deform_mode);
+    auto [u, u_out] = inter_map(w.aspp.oc, w.icp);                   // (ASPPDeformable(inter, None): out_channels = inter_channels)
+    aspp_forward(c, w.aspp, t, u_out, deform_mode);
     run_conv(c, w.conv_out, u, out, nullptr, 0, 0, out_f32);         // conv_out + bn_out (no ReLU)
     c.arena->release(mk);
 }
 
 void aspp_forward(Ctx& c, const ASPPW& a, const Map& t, const Map& u, int deform_mode) {
-    if (t.C != 64 || t.ld != 64 || t.coff || u.C != 64 || u.ld != 64 || u.coff || u.B != t.B || u.H != t.H || u.W != t.W)
-        fail(BRN_ERR_INVALID_ARG, "ASPPDeformable runs on whole 64-channel maps");
+    if (t.C != a.icp || t.ld != a.icp || t.coff || u.C != a.oc || u.B != t.B || u.H != t.H || u.W != t.W)
+        fail(BRN_ERR_INVALID_ARG, "ASPPDeformable(%d -> %d): input map [C %d, ld %d, coff %d] must be a whole map of %d channels, output map C %d", a.ic, a.oc, t.C,
+             t.ld, t.coff, a.icp, u.C);
     const size_t mk = c.arena->mark();
-    const int B = t.B, H = t.H, W = t.W, M = B * H * W;
+    const int B = t.B, H = t.H, W = t.W, M = B * H * W, IC = a.icp, OC = a.oc;
     const int region0 = c.region;
     c.region = REGION_ASPP;
     Map cat = new_map(c, B, H, W, 1024);                             // [aspp1 | deform k1 | k3 | k7]; pooled branch -> bias
-    float* g0 = c.arena->alloc((size_t)B * 64);
+    float* g0 = c.arena->alloc((size_t)B * IC);
     float* g1 = c.arena->alloc((size_t)B * 256);
-    float* gb = c.arena->alloc((size_t)B * 64);
-    float* gscr = c.arena->alloc(gap_scratch_floats(B, H * W, 64));
+    float* gb = c.arena->alloc((size_t)B * OC);
+    float* gscr = c.arena->alloc(gap_scratch_floats(B, H * W, IC));
     {
         // the branches only share their input t: each runs on its own stream (the 7 x 7 branch, the longest, stays on the main one)
         ArenaHold hold(*c.arena);
@@ -553,14 +563,14 @@ void aspp_forward(Ctx& c, const ASPPW& a, const Map& t, const Map& u, int deform
             // pooled branch: mean over H then W (aspp.rs:314), 1x1 conv (no bias) + BN + ReLU, nearest-broadcast (aspp.rs:315-318)
             Branch br(c, 2);
             if (!c.dry) {
-                Bracket b(c, FAM_ELEMENTWISE, 0.0, 4.0 * M * 64);
-                BRN_LAUNCH(launch_gap_nhwc(t.p, B, H * W, 64, 64, 0, gscr, g0, c.stream, c.bf16));
-                BRN_LAUNCH(launch_small_fc(g0, B, 64, a.gap_w, 64, 0, 256, a.gap_scale, a.gap_shift, ACT_RELU, g1, c.stream));
-                BRN_LAUNCH(launch_small_fc(g1, B, 256, a.conv1_full, 1280, 1024, 64, nullptr, nullptr, ACT_NONE, gb, c.stream));
+                Bracket b(c, FAM_ELEMENTWISE, 0.0, 4.0 * M * IC);
+                BRN_LAUNCH(launch_gap_nhwc(t.p, B, H * W, IC, IC, 0, gscr, g0, c.stream, c.bf16));
+                BRN_LAUNCH(launch_small_fc(g0, B, IC, a.gap_w, IC, 0, 256, a.gap_scale, a.gap_shift, ACT_RELU, g1, c.stream));
+                BRN_LAUNCH(launch_small_fc(g1, B, 256, a.conv1_full, 1280, 1024, OC, nullptr, nullptr, ACT_NONE, gb, c.stream));
             }
         }
         if (deform_mode == BRN_DEFORM_REFERENCE_CPU) {
-            { Branch br(c, 0); run_gemm(c, a.k1pair, t.p, M, 64, cat.p, 1024, 0); }           // aspp1 + aspp_deforms.0 (regular 1x1, BN, ReLU)
+            { Branch br(c, 0); run_gemm(c, a.k1pair, t.p, M, IC, cat.p, 1024, 0); }          // aspp1 + aspp_deforms.0 (regular 1x1, BN, ReLU)
             { Branch br(c, 1); run_conv(c, a.d[2].regular, t, cat.window(512, 256)); }       // k3
             run_conv(c, a.d[3].regular, t, cat.window(768, 256));                             // k7
         } else {
@@ -581,7 +591,7 @@ void aspp_forward(Ctx& c, const ASPPW& a, const Map& t, const Map& u, int deform
         }
         join_branches(c, AUX_ASPP_MASK);
     }
-    run_gemm(c, a.conv1_main, cat.p, M, 1024, u.p, 64, 0, nullptr, 0, 0, gb, H * W);   // conv1 + bn1 + relu (aspp.rs:329-331)
+    run_gemm(c, a.conv1_main, cat.p, M, 1024, u.p, u.ld, u.coff, nullptr, 0, 0, gb, H * W);   // conv1 + bn1 + relu (aspp.rs:329-331)
     c.region = region0;
     c.arena->release(mk);
 }

@@ -139,9 +139,11 @@ struct ASPPW {             // ASPPDeformable (aspp.rs:227-333)
     DeformW d[4];          // aspp1, deform k1, k3, k7
     float* gap_w = nullptr; float* gap_scale = nullptr; float* gap_shift = nullptr;   // global_avg_pool.1/.2
     float* conv1_full = nullptr;   // [64][1280] (for the pooled branch's contribution)
-    GemmW conv1_main;      // [64][1024] + bn1 + relu
+    GemmW conv1_main;      // [oc][1024] + bn1 + relu
+    int ic = 64, icp = 64, oc = 64;   // in_channels, the same rounded up to the kernels' channel granule (the input map carries icp channels), out_channels
 };
-struct DecBlkW { GemmW conv_in; ASPPW aspp; GemmW conv_out; int cin = 0, cout = 0; bool has_aspp = true; /* dec_att is Some (decoder.rs:107-111) */ };
+struct DecBlkW { GemmW conv_in; ASPPW aspp; GemmW conv_out; int cin = 0, cout = 0; bool has_aspp = true; /* dec_att is Some (decoder.rs:107-111) */
+                 int ic = 64, icp = 64; /* inter_channels and the channel count of the maps between the convs (granule-padded) */ };
 struct SimpleConvsW { GemmW conv1, conv_out; };
 struct DecoderW {
     SimpleConvsW ipt[5];   // ipt_blk2..5 at [1..4]; ipt_blk1 ([0]) is composed into head_k / head_b
@@ -214,9 +216,11 @@ struct Model {
 };
 
 void build_swin_weights(const WeightTable& wt, const std::string& prefix, const brn_config& cfg, DeviceOwner& own, SwinW& out);
-void build_aspp_weights(const WeightTable& wt, const std::string& prefix, int deform_mode, DeviceOwner& own, ASPPW& out);
+// ASPPDeformable::new(in_channels, out_channels (0 = in_channels), vb.pp(prefix)) (aspp.rs:236-300)
+void build_aspp_weights(const WeightTable& wt, const std::string& prefix, int deform_mode, DeviceOwner& own, ASPPW& out, int in_channels = 64,
+                        int out_channels = 0);
 void build_decblk_weights(const WeightTable& wt, const std::string& prefix, int cin, int cout, int deform_mode, DeviceOwner& own, DecBlkW& out,
-                          bool use_aspp = true);
+                          bool use_aspp = true, int inter_channels = 64 /* decoder.rs:94-98: 64, or in_channels / 4 when inter_channels_adaptive */);
 void build_decoder_weights(const WeightTable& wt, const std::string& prefix, const brn_config& cfg, DeviceOwner& own, DecoderW& out);
 
 // generic weight repack helpers (also used by the op-level entry points)
@@ -259,7 +263,7 @@ void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int 
 void swin_attention(Ctx& c, const SwinBlockW& blk, const float* xn, int B, int H, int W, int C, int shift,
                     float* y, const float* residual, int window = 12);
 void decblk_forward(Ctx& c, const DecBlkW& w, const Map& in, const Map& out, int deform_mode, int out_f32 = 0 /* BRN_BF16: `out` is an fp32 map */);
-// ASPPDeformable::forward (aspp.rs:303-333) on a 64-channel map t -> 64-channel map u (both whole maps: ld == C == 64)
+// ASPPDeformable::forward (aspp.rs:303-333) on a whole map t of a.icp channels (the first a.ic real, the rest zero) -> map u of a.oc channels
 void aspp_forward(Ctx& c, const ASPPW& a, const Map& t, const Map& u, int deform_mode);
 // the decoder's concat maps (birefnet.rs:332,347,362) — allocated by the caller when the image-patch convolutions that fill their
 // last channels are enqueued early, beside the backbone (model_forward)

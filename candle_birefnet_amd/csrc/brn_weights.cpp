@@ -328,24 +328,29 @@ static GemmW conv_bn(const WeightTable& wt, const std::string& conv, bool has_bi
 }
 
 void build_decblk_weights(const WeightTable& wt, const std::string& p, int cin, int cout, int deform_mode, DeviceOwner& own,
-                          DecBlkW& out, bool use_aspp) {
-    const int IC = 64;             // inter_channels (decoder.rs:96)
-    out.cin = cin; out.cout = cout; out.has_aspp = use_aspp;
+                          DecBlkW& out, bool use_aspp, int inter_channels) {
+    const int IC = inter_channels;  // decoder.rs:94-98
+    if (IC < 1) fail(BRN_ERR_INVALID_ARG, "decoder block inter_channels %d", IC);
+    const int gran = g_build_planes == BUILD_BF16 ? 64 : 32;
+    out.cin = cin; out.cout = cout; out.has_aspp = use_aspp; out.ic = IC; out.icp = roundup(IC, gran);
     // The channels-last convs read whole 32-channel granules (64 in the bf16-storage mode, where e.g. decoder_block1's 480 is padded so
-    // that the conv runs chunk-major): an input channel count off the granule is padded with zero weights to the next multiple; the
-    // caller's map then carries conv_in.Cinp channels, the pad ones zero.  (Every block of the model has in_channels % 32 == 0.)
-    const int cin_pad = roundup(cin, g_build_planes == BUILD_BF16 ? 64 : 32);
+    // that the conv runs chunk-major): a channel count off the granule is padded with zero weights to the next multiple; the map then
+    // carries that many channels, the pad ones zero (conv_in's pad OUTPUT channels have zero weights, scale and shift).  Every block of
+    // the model has in_channels % 32 == 0 and inter_channels = 64.
+    const int cin_pad = roundup(cin, gran);
     out.conv_in = conv_bn(wt, p + "conv_in", true, p + "bn_in", IC, cin, cin_pad, 3, 1, ACT_RELU, own);
-    out.conv_out = conv_bn(wt, p + "conv_out", true, p + "bn_out", cout, IC, IC, 3, 1, ACT_NONE, own);   // no ReLU (decoder.rs:138-139)
-    if (use_aspp) build_aspp_weights(wt, p + "dec_att.", deform_mode, own, out.aspp);                     // decoder.rs:107-111
+    out.conv_out = conv_bn(wt, p + "conv_out", true, p + "bn_out", cout, IC, out.icp, 3, 1, ACT_NONE, own);   // no ReLU (decoder.rs:138-139)
+    if (use_aspp) build_aspp_weights(wt, p + "dec_att.", deform_mode, own, out.aspp, IC, 0);                    // decoder.rs:107-111
 }
 
-// ASPPDeformable::new (aspp.rs:236-300) for in_channels = 64 under prefix `ap`
-void build_aspp_weights(const WeightTable& wt, const std::string& ap, int deform_mode, DeviceOwner& own, ASPPW& a) {
-    const int IC = 64, PL = 256;   // in / out channels of the module inside BasicDecBlk (decoder.rs:96,107-111), ASPP planes (aspp.rs:243)
+// ASPPDeformable::new (aspp.rs:236-300) under prefix `ap`: in_channels IC (64 inside the model's BasicDecBlk), out_channels OC
+void build_aspp_weights(const WeightTable& wt, const std::string& ap, int deform_mode, DeviceOwner& own, ASPPW& a, int in_channels, int out_channels) {
+    const int IC = in_channels, OC = out_channels > 0 ? out_channels : in_channels, PL = 256;   // aspp.rs:242-243
+    if (IC < 1) fail(BRN_ERR_INVALID_ARG, "ASPPDeformable in_channels %d", IC);
+    const int ICP = roundup(IC, g_build_planes == BUILD_BF16 ? 64 : 32);
+    a.ic = IC; a.icp = ICP; a.oc = OC;
     const int ks[4] = {1, 1, 3, 7};
     const std::string mods[4] = {ap + "aspp1.", ap + "aspp_deforms.0.", ap + "aspp_deforms.1.", ap + "aspp_deforms.2."};
-    std::vector<float> pair_w, pair_sc, pair_sh;
     for (int i = 0; i < 4; ++i) {
         const int k = ks[i], kk = k * k;
         DeformW& d = a.d[i];
@@ -356,7 +361,7 @@ void build_aspp_weights(const WeightTable& wt, const std::string& ap, int deform
         const float* ob = wt.get(cp + "offset_conv.bias", {2 * kk})->data;
         const float* mw = wt.get(cp + "modulator_conv.weight", {kk, IC, k, k})->data;
         const float* mb = wt.get(cp + "modulator_conv.bias", {kk})->data;
-        d.regular = conv_bn(wt, cp + "regular_conv", false, mods[i] + "bn", PL, IC, IC, k, k / 2, ACT_RELU, own);
+        d.regular = conv_bn(wt, cp + "regular_conv", false, mods[i] + "bn", PL, IC, ICP, k, k / 2, ACT_RELU, own);
         if (deform_mode == BRN_DEFORM_DEFORMABLE) {
             d.regular.mode = GEMM_DEFORM_NHWC;
             attach_deform_frags(own, d.regular, wt.get(cp + "regular_conv.weight", {PL, IC, k, k})->data);
@@ -365,18 +370,20 @@ void build_aspp_weights(const WeightTable& wt, const std::string& ap, int deform
             memcpy(w3.data() + (size_t)2 * kk * IC * kk, mw, (size_t)kk * IC * kk * sizeof(float));
             memcpy(b3.data(), ob, (size_t)2 * kk * sizeof(float));
             memcpy(b3.data() + 2 * kk, mb, (size_t)kk * sizeof(float));
-            d.offmod = make_conv_nhwc(own, w3.data(), b3.data(), 3 * kk, IC, IC, k, k, 1, k / 2, 1);
+            d.offmod = make_conv_nhwc(own, w3.data(), b3.data(), 3 * kk, IC, ICP, k, k, 1, k / 2, 1);
         }
     }
     if (deform_mode == BRN_DEFORM_REFERENCE_CPU) {
-        // aspp1 and aspp_deforms.0 are both plain 1x1 64->256 convs of the same input on the CPU path
-        // (aspp.rs:183-185): one GEMM with N = 512 writes both concat slices.
+        // aspp1 and aspp_deforms.0 are both plain 1x1 IC->256 convs of the same input on the CPU path
+        // (aspp.rs:183-185): one GEMM with N = 512 writes both concat slices (K = ICP: zero columns for the pad channels).
         const float* w0 = wt.get(mods[0] + "atrous_conv.regular_conv.weight", {PL, IC, 1, 1})->data;
         const float* w1 = wt.get(mods[1] + "atrous_conv.regular_conv.weight", {PL, IC, 1, 1})->data;
-        std::vector<float> w2((size_t)2 * PL * IC);
-        memcpy(w2.data(), w0, (size_t)PL * IC * sizeof(float));
-        memcpy(w2.data() + (size_t)PL * IC, w1, (size_t)PL * IC * sizeof(float));
-        a.k1pair = make_linear(own, w2.data(), nullptr, 2 * PL, IC);
+        std::vector<float> w2((size_t)2 * PL * ICP, 0.f);
+        for (int n = 0; n < PL; ++n) {
+            memcpy(&w2[(size_t)n * ICP], &w0[(size_t)n * IC], (size_t)IC * sizeof(float));
+            memcpy(&w2[(size_t)(PL + n) * ICP], &w1[(size_t)n * IC], (size_t)IC * sizeof(float));
+        }
+        a.k1pair = make_linear(own, w2.data(), nullptr, 2 * PL, ICP);
         BNHost h0 = get_bn(wt, mods[0] + "bn", PL), h1 = get_bn(wt, mods[1] + "bn", PL);
         std::vector<float> g(2 * PL), b(2 * PL), m(2 * PL), v(2 * PL);
         for (int n = 0; n < PL; ++n) {
@@ -386,10 +393,12 @@ void build_aspp_weights(const WeightTable& wt, const std::string& ap, int deform
         fold_bn(own, a.k1pair, nullptr, g.data(), b.data(), m.data(), v.data(), 1e-5f);
         a.k1pair.act = ACT_RELU;
     }
-    // global_avg_pool.1 (conv, no bias) + .2 (BN) (aspp.rs:271-278)
+    // global_avg_pool.1 (conv, no bias) + .2 (BN) (aspp.rs:271-278); rows padded to ICP like the pooled vector
     {
         const float* gw = wt.get(ap + "global_avg_pool.1.weight", {PL, IC, 1, 1})->data;
-        a.gap_w = own.upload(gw, (size_t)PL * IC);
+        std::vector<float> gp((size_t)PL * ICP, 0.f);
+        for (int n = 0; n < PL; ++n) memcpy(&gp[(size_t)n * ICP], &gw[(size_t)n * IC], (size_t)IC * sizeof(float));
+        a.gap_w = own.upload(gp);
         BNHost h = get_bn(wt, ap + "global_avg_pool.2", PL);
         std::vector<float> sc(PL), sh(PL);
         for (int n = 0; n < PL; ++n) {
@@ -398,15 +407,15 @@ void build_aspp_weights(const WeightTable& wt, const std::string& ap, int deform
         }
         a.gap_scale = own.upload(sc); a.gap_shift = own.upload(sh);
     }
-    // conv1 1x1 1280->64 no bias + bn1 + ReLU (aspp.rs:282-290, 329-331).  The first 1024 input channels are the four
+    // conv1 1x1 1280->OC no bias + bn1 + ReLU (aspp.rs:282-290, 329-331).  The first 1024 input channels are the four
     // spatial branches (a GEMM); the last 256 are the pooled branch, constant over the map -> a per-image bias.
     {
-        const float* cw = wt.get(ap + "conv1.weight", {IC, 5 * PL, 1, 1})->data;
-        a.conv1_full = own.upload(cw, (size_t)IC * 5 * PL);
-        std::vector<float> mainw((size_t)IC * 4 * PL);
-        for (int o = 0; o < IC; ++o) memcpy(&mainw[(size_t)o * 4 * PL], &cw[(size_t)o * 5 * PL], (size_t)4 * PL * sizeof(float));
-        a.conv1_main = make_linear(own, mainw.data(), nullptr, IC, 4 * PL);
-        BNHost h = get_bn(wt, ap + "bn1", IC);
+        const float* cw = wt.get(ap + "conv1.weight", {OC, 5 * PL, 1, 1})->data;
+        a.conv1_full = own.upload(cw, (size_t)OC * 5 * PL);
+        std::vector<float> mainw((size_t)OC * 4 * PL);
+        for (int o = 0; o < OC; ++o) memcpy(&mainw[(size_t)o * 4 * PL], &cw[(size_t)o * 5 * PL], (size_t)4 * PL * sizeof(float));
+        a.conv1_main = make_linear(own, mainw.data(), nullptr, OC, 4 * PL);
+        BNHost h = get_bn(wt, ap + "bn1", OC);
         fold_bn(own, a.conv1_main, nullptr, h.g, h.b, h.m, h.v, 1e-5f);
         a.conv1_main.act = ACT_RELU;
     }

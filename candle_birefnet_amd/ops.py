@@ -98,34 +98,35 @@ def patch_merging(x, H, W, norm_g, norm_b, reduction_w, device=0):
     return y
 
 
-def aspp_deformable(x, tensors, mode="reference_cpu", prefix="", device=0):
-    """ASPPDeformable::forward (aspp.rs:303-333) on a 64-channel NCHW map; `tensors`: name -> host array of the module's weights
-    under `prefix` (SURVEY.md App. A <ASPP>).  mode: "reference_cpu" (aspp.rs:183-185) or "deformable" (aspp.rs:58-165)."""
+def aspp_deformable(x, tensors, mode="reference_cpu", prefix="", out_channels=None, device=0):
+    """ASPPDeformable::new(in_channels, out_channels, vb.pp(prefix)) + forward (aspp.rs:236-333) on an NCHW map; `tensors`: name -> host
+    array of the module's weights under `prefix` (SURVEY.md App. A <ASPP>; BasicDecBlk builds it with 64 -> 64).  mode: "reference_cpu"
+    (aspp.rs:183-185) or "deformable" (aspp.rs:58-165).  out_channels None = in_channels (aspp.rs:242)."""
     from .birefnet import _named_array
     B, Cc, H, W = (int(v) for v in x.shape)
-    if Cc != 64:
-        raise ValueError(f"ASPPDeformable inside BasicDecBlk runs on 64 channels, got {Cc}")
+    oc = int(out_channels) if out_channels else Cc
     arr, keep_w = _named_array(tensors)
     px, loc, keep, _ = T.as_arg(x)
-    y = T.alloc_like(keep, (B, 64, H, W))
+    y = T.alloc_like(keep, (B, oc, H, W))
     m = {"reference_cpu": _ffi.BRN_DEFORM_REFERENCE_CPU, "deformable": _ffi.BRN_DEFORM_DEFORMABLE}[mode]
-    _ffi.check(_ffi.lib.brn_aspp_deformable_forward(arr, len(arr), prefix.encode(), m, px, B, H, W, T.ptr_of(y), loc, T.device_of(keep, device),
+    _ffi.check(_ffi.lib.brn_aspp_deformable_forward(arr, len(arr), prefix.encode(), Cc, oc, m, px, B, H, W, T.ptr_of(y), loc, T.device_of(keep, device),
                                                     T.stream_of(keep)))
     del keep_w
     return y
 
 
-def decblk(x, tensors, out_channels, mode="reference_cpu", prefix="", use_aspp=True, device=0):
-    """BasicDecBlk::new(in_channels, out_channels, &DecoderConfig { use_aspp_deformable: use_aspp, .. }, vb.pp(prefix)) + forward
-    (decoder.rs:78-141) on an NCHW map [B,in_channels,H,W] -> [B,out_channels,H,W]; `tensors`: name -> host array of the block's
-    weights under `prefix` (SURVEY.md App. A <DecBlk>)."""
+def decblk(x, tensors, out_channels, mode="reference_cpu", prefix="", use_aspp=True, inter_channels_adaptive=False, device=0):
+    """BasicDecBlk::new(in_channels, out_channels, &DecoderConfig { use_aspp_deformable: use_aspp, inter_channels_adaptive }, vb.pp(prefix))
+    + forward (decoder.rs:78-141) on an NCHW map [B,in_channels,H,W] -> [B,out_channels,H,W]; `tensors`: name -> host array of the
+    block's weights under `prefix` (SURVEY.md App. A <DecBlk>).  inter_channels = 64, or in_channels // 4 when adaptive (decoder.rs:94-98)."""
     from .birefnet import _named_array
     B, Cc, H, W = (int(v) for v in x.shape)
     arr, keep_w = _named_array(tensors)
     px, loc, keep, _ = T.as_arg(x)
     y = T.alloc_like(keep, (B, int(out_channels), H, W))
     m = {"reference_cpu": _ffi.BRN_DEFORM_REFERENCE_CPU, "deformable": _ffi.BRN_DEFORM_DEFORMABLE}[mode]
-    _ffi.check(_ffi.lib.brn_decblk_forward(arr, len(arr), prefix.encode(), Cc, int(out_channels), int(bool(use_aspp)), m, px, B, H, W, T.ptr_of(y), loc,
+    inter = Cc // 4 if inter_channels_adaptive else 64
+    _ffi.check(_ffi.lib.brn_decblk_forward(arr, len(arr), prefix.encode(), Cc, int(out_channels), inter, int(bool(use_aspp)), m, px, B, H, W, T.ptr_of(y), loc,
                                            T.device_of(keep, device), T.stream_of(keep)))
     del keep_w
     return y

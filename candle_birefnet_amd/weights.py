@@ -53,19 +53,27 @@ def _conv(p, O, Cin, k, bias=True, kind="conv_w"):
     return [(p + ".weight", (O, Cin, k, k), kind)] + ([(p + ".bias", (O,), "bias")] if bias else [])
 
 
-def _decblk(p, cin, cout):
-    """BasicDecBlk::new + ASPPDeformable::new (decoder.rs:104-114, aspp.rs:247-290)."""
-    s = _conv(p + "conv_in", 64, cin, 3) + _bn(p + "bn_in", 64)
-    ap = p + "dec_att."
+def _aspp(ap, ic=64, oc=None):
+    """ASPPDeformable::new(ic, oc, vb.pp(ap)) (aspp.rs:247-290)"""
+    oc = oc or ic
+    s = []
     for mod, k in (("aspp1", 1), ("aspp_deforms.0", 1), ("aspp_deforms.1", 3), ("aspp_deforms.2", 7)):
         cp = f"{ap}{mod}.atrous_conv."
-        s += _conv(cp + "offset_conv", 2 * k * k, 64, k, kind="offset_w")
-        s += _conv(cp + "modulator_conv", k * k, 64, k, kind="mod_w")
-        s += _conv(cp + "regular_conv", 256, 64, k, bias=False)
+        s += _conv(cp + "offset_conv", 2 * k * k, ic, k, kind="offset_w")
+        s += _conv(cp + "modulator_conv", k * k, ic, k, kind="mod_w")
+        s += _conv(cp + "regular_conv", 256, ic, k, bias=False)
         s += _bn(f"{ap}{mod}.bn", 256)
-    s += _conv(ap + "global_avg_pool.1", 256, 64, 1, bias=False) + _bn(ap + "global_avg_pool.2", 256)
-    s += _conv(ap + "conv1", 64, 1280, 1, bias=False) + _bn(ap + "bn1", 64)
-    s += _conv(p + "conv_out", cout, 64, 3) + _bn(p + "bn_out", cout)
+    s += _conv(ap + "global_avg_pool.1", 256, ic, 1, bias=False) + _bn(ap + "global_avg_pool.2", 256)
+    s += _conv(ap + "conv1", oc, 1280, 1, bias=False) + _bn(ap + "bn1", oc)
+    return s
+
+
+def _decblk(p, cin, cout, inter=64, use_aspp=True):
+    """BasicDecBlk::new + ASPPDeformable::new (decoder.rs:104-114, aspp.rs:247-290)."""
+    s = _conv(p + "conv_in", inter, cin, 3) + _bn(p + "bn_in", inter)
+    if use_aspp:
+        s += _aspp(p + "dec_att.", inter)
+    s += _conv(p + "conv_out", cout, inter, 3) + _bn(p + "bn_out", cout)
     return s
 
 

@@ -234,25 +234,26 @@ brn_status brn_deform_conv2d_forward(const float* x, int B, int C, int H, int W,
                                      const float* w, const float* bias, int O, int k, int stride, int pad,
                                      int mode, float* y, brn_mem loc, int device_ordinal, void* stream);
 
-/* ASPPDeformable::new(64, None, &[1, 3, 7]) + forward (aspp.rs:236-333) as BasicDecBlk builds it (decoder.rs:107-111): the five
- * branches on a 64-channel map (aspp1 and aspp_deforms.{0,1,2} = DeformConvASPP k 1,1,3,7 -> 256, BN, ReLU; global average pool
- * -> 1x1 -> BN -> ReLU -> broadcast), concat 1280, conv1 1x1 (no bias) + bn1 + ReLU.  weights: the module's tensors under
- * `prefix` ("aspp1.atrous_conv.offset_conv.weight", ..., "conv1.weight", "bn1.*"; SURVEY.md App. A <ASPP>); mode = brn_deform_mode.
- * x, y: [B,64,H,W] NCHW. */
-brn_status brn_aspp_deformable_forward(const brn_named_tensor* weights, size_t n_weights, const char* prefix, int mode,
-                                       const float* x, int B, int H, int W, float* y, brn_mem loc,
+/* ASPPDeformable::new(in_channels, out_channels, vb.pp(prefix)) + forward (aspp.rs:236-333; BasicDecBlk builds it with
+ * (64, None), decoder.rs:107-111): five branches on the map (aspp1 and aspp_deforms.{0,1,2} = DeformConvASPP k 1,1,3,7 -> 256, BN, ReLU;
+ * global average pool -> 1x1 -> BN -> ReLU -> broadcast), concat 1280, conv1 1x1 (no bias) + bn1 + ReLU.  weights: the module's tensors
+ * under `prefix` ("aspp1.atrous_conv.offset_conv.weight", ..., "conv1.weight", "bn1.*"; SURVEY.md App. A <ASPP>); mode =
+ * brn_deform_mode; out_channels 0 = None = in_channels (aspp.rs:242).  x [B,in_channels,H,W] -> y [B,out_channels,H,W], NCHW; any widths. */
+brn_status brn_aspp_deformable_forward(const brn_named_tensor* weights, size_t n_weights, const char* prefix, int in_channels,
+                                       int out_channels, int mode, const float* x, int B, int H, int W, float* y, brn_mem loc,
                                        int device_ordinal, void* stream);
 
 /* BasicDecBlk::new(in_channels, out_channels, &DecoderConfig, vb.pp(prefix)) + forward (decoder.rs:78-141), the block behind
  * SqueezeModule and decoder_block{4,3,2,1}: conv_in 3x3 (in_channels -> 64, bias) + bn_in + ReLU -> ASPPDeformable(64) (use_aspp != 0:
  * DecoderConfig::use_aspp_deformable, decoder.rs:107-111; 0 = dec_att is None) -> conv_out 3x3 (64 -> out_channels, bias) + bn_out (no
- * ReLU).  inter_channels is the fixed 64 of DecoderConfig::default() (inter_channels_adaptive = false, decoder.rs:21,94-98).
+ * ReLU).  inter_channels: 64 (DecoderConfig::default(), what BiRefNet builds) or in_channels / 4 (inter_channels_adaptive,
+ * decoder.rs:94-98); 0 = 64.
  * weights: "conv_in.weight|bias", "bn_in.*", "dec_att.<ASPP>", "conv_out.weight|bias", "bn_out.*" under `prefix` (SURVEY.md App. A
- * <DecBlk>); mode = brn_deform_mode.  x [B,in_channels,H,W] -> y [B,out_channels,H,W], NCHW; any in_channels (the map is padded
- * to the kernels' channel granule inside). */
+ * <DecBlk>); mode = brn_deform_mode.  x [B,in_channels,H,W] -> y [B,out_channels,H,W], NCHW; any widths (maps are padded to the
+ * kernels' channel granule inside). */
 brn_status brn_decblk_forward(const brn_named_tensor* weights, size_t n_weights, const char* prefix, int in_channels,
-                              int out_channels, int use_aspp, int mode, const float* x, int B, int H, int W, float* y,
-                              brn_mem loc, int device_ordinal, void* stream);
+                              int out_channels, int inter_channels, int use_aspp, int mode, const float* x, int B, int H, int W,
+                              float* y, brn_mem loc, int device_ordinal, void* stream);
 
 /* ---- image pre/post-processing: the steps either side of forward_logits in examples/infer_image.rs ------ */
 /* infer_image.rs:44-67.  `img.resize_exact(S, S, FilterType::Triangle)` -> `to_rgb8()` -> (v/255 - mean) / std with the

@@ -575,7 +575,7 @@ static Tensor deform_conv_aspp(const Tensor& x, const Weights& w, const std::str
 }
 
 // ASPPDeformable::forward (aspp.rs:303-333)
-static Tensor aspp_deformable(const Tensor& x, const Weights& w, const std::string& p, int mode) {
+static Tensor aspp_deformable(const Tensor& x, const Weights& w, const std::string& p, int mode, int64_t out_channels = 0) {
     const int64_t B = x.dim(0), C = x.dim(1), H = x.dim(2), W = x.dim(3);
     auto module = [&](const std::string& q, int64_t k) {              // ASPPModuleDeformable::forward (aspp.rs:217-223)
         Tensor t = deform_conv_aspp(x, w, q + "atrous_conv.", k, mode);
@@ -597,14 +597,15 @@ static Tensor aspp_deformable(const Tensor& x, const Weights& w, const std::stri
 #pragma omp parallel for
     for (int64_t bc = 0; bc < B * 256; ++bc) std::fill(x5u.p() + bc * H * W, x5u.p() + (bc + 1) * H * W, x5.d[bc]);
     Tensor cat = cat_channels({&x1, &d0, &d1, &d2, &x5u});            // aspp.rs:321-327
-    Tensor out = conv_named(cat, w, p + "conv1", C, 1, 0, false);     // out_channels = in_channels (aspp.rs:242)
+    const int64_t OC = out_channels > 0 ? out_channels : C;           // out_channels.unwrap_or(in_channels) (aspp.rs:242)
+    Tensor out = conv_named(cat, w, p + "conv1", OC, 1, 0, false);
     bn_named_(out, w, p + "bn1"); relu_(out);
     return out;
 }
 
 // BasicDecBlk::forward (decoder.rs:126-141)
-static Tensor dec_blk(const Tensor& x, const Weights& w, const std::string& p, int64_t cout, int mode, bool use_aspp = true) {
-    Tensor t = conv_named(x, w, p + "conv_in", 64, 3, 1, true);
+static Tensor dec_blk(const Tensor& x, const Weights& w, const std::string& p, int64_t cout, int mode, bool use_aspp = true, int64_t inter = 64) {
+    Tensor t = conv_named(x, w, p + "conv_in", inter, 3, 1, true);    // inter_channels: 64, or in_channels / 4 (decoder.rs:94-98)
     bn_named_(t, w, p + "bn_in"); relu_(t);
     if (use_aspp) t = aspp_deformable(t, w, p + "dec_att.", mode);    // dec_att is None when DecoderConfig::use_aspp_deformable is false (decoder.rs:107-111,131-135)
     t = conv_named(t, w, p + "conv_out", cout, 3, 1, true);
@@ -798,20 +799,21 @@ int orc_deform_conv2d(const float* x, int B, int C, int H, int W, const float* o
     });
 }
 // ASPPDeformable::forward (aspp.rs:303-333) on a 64-channel map; weights under `prefix`
-int orc_aspp(const brn_named_tensor* weights, size_t n, const char* prefix, int mode, const float* x, int B, int H, int W_, float* y) {
+int orc_aspp(const brn_named_tensor* weights, size_t n, const char* prefix, int in_channels, int out_channels, int mode, const float* x, int B, int H,
+             int W_, float* y) {
     return guarded([&] {
         Weights w(weights, n);
-        Tensor t = aspp_deformable(from_ptr(x, {B, 64, H, W_}), w, prefix ? prefix : "", mode);
+        Tensor t = aspp_deformable(from_ptr(x, {B, in_channels, H, W_}), w, prefix ? prefix : "", mode, out_channels);
         memcpy(y, t.p(), (size_t)t.numel() * sizeof(float));
     });
 }
 // BasicDecBlk::new(in_channels, out_channels, &DecoderConfig{use_aspp_deformable, inter_channels_adaptive: false}, vb.pp(prefix)) + forward
 // (decoder.rs:87-141)
-int orc_decblk(const brn_named_tensor* weights, size_t n, const char* prefix, int cin, int cout, int use_aspp, int mode, const float* x, int B, int H,
-               int W_, float* y) {
+int orc_decblk(const brn_named_tensor* weights, size_t n, const char* prefix, int cin, int cout, int inter, int use_aspp, int mode, const float* x, int B,
+               int H, int W_, float* y) {
     return guarded([&] {
         Weights w(weights, n);
-        Tensor t = dec_blk(from_ptr(x, {B, cin, H, W_}), w, prefix ? prefix : "", cout, mode, use_aspp != 0);
+        Tensor t = dec_blk(from_ptr(x, {B, cin, H, W_}), w, prefix ? prefix : "", cout, mode, use_aspp != 0, inter > 0 ? inter : 64);
         memcpy(y, t.p(), (size_t)t.numel() * sizeof(float));
     });
 }

@@ -217,23 +217,25 @@ def deform_conv2d(x, offset_w, offset_b, mod_w, mod_b, w, bias, k, stride, pad, 
     return y
 
 
-def aspp_deformable(x, weights, mode=0, prefix=""):
-    """ASPPDeformable::forward (aspp.rs:303-333): x [B,64,H,W]; mode 0 = reference_cpu, 1 = deformable"""
+def aspp_deformable(x, weights, mode=0, prefix="", out_channels=None):
+    """ASPPDeformable::forward (aspp.rs:303-333): x [B,in_channels,H,W]; mode 0 = reference_cpu, 1 = deformable; out_channels None = in_channels"""
     x = _f(x)
-    B, _, H, W = x.shape
+    B, ic, H, W = x.shape
+    oc = int(out_channels) if out_channels else ic
     arr, n, keep = named(weights)
-    y = np.empty((B, 64, H, W), np.float32)
-    _chk(lib().orc_aspp(arr, C.c_size_t(n), prefix.encode(), int(mode), _p(x), B, H, W, _p(y)))
+    y = np.empty((B, oc, H, W), np.float32)
+    _chk(lib().orc_aspp(arr, C.c_size_t(n), prefix.encode(), ic, oc, int(mode), _p(x), B, H, W, _p(y)))
     return y
 
 
-def decblk(x, weights, out_channels, mode=0, prefix="", use_aspp=True):
+def decblk(x, weights, out_channels, mode=0, prefix="", use_aspp=True, inter_channels_adaptive=False):
     """BasicDecBlk::forward (decoder.rs:126-141): x [B,Cin,H,W] -> [B,out_channels,H,W]; weights under `prefix`"""
     x = _f(x)
     B, cin, H, W = x.shape
     arr, n, keep = named(weights)
     y = np.empty((B, out_channels, H, W), np.float32)
-    _chk(lib().orc_decblk(arr, C.c_size_t(n), prefix.encode(), cin, int(out_channels), int(bool(use_aspp)), int(mode), _p(x), B, H, W, _p(y)))
+    inter = cin // 4 if inter_channels_adaptive else 64
+    _chk(lib().orc_decblk(arr, C.c_size_t(n), prefix.encode(), cin, int(out_channels), inter, int(bool(use_aspp)), int(mode), _p(x), B, H, W, _p(y)))
     return y
 
 

@@ -113,10 +113,10 @@ impl Module for ASPP {
     }
 }
 
-/// every tensor `ASPPDeformable::new(64, None, vb)` asks its VarBuilder for (aspp.rs:39-45, 247-290), names relative to `vb`
-pub fn aspp_weight_spec() -> Vec<(String, Vec<usize>)> {
+/// every tensor `ASPPDeformable::new(ic, Some(oc), vb)` asks its VarBuilder for (aspp.rs:39-45, 247-290), names relative to `vb`
+pub fn aspp_weight_spec_for(ic: usize, oc: usize) -> Vec<(String, Vec<usize>)> {
     let mut s: Vec<(String, Vec<usize>)> = Vec::new();
-    let (ic, pl) = (64usize, 256usize);
+    let pl = 256usize;
     let mut bn = |s: &mut Vec<(String, Vec<usize>)>, p: &str, c: usize| {
         for leaf in ["weight", "bias", "running_mean", "running_var"] {
             s.push((format!("{p}.{leaf}"), vec![c]));
@@ -133,42 +133,48 @@ pub fn aspp_weight_spec() -> Vec<(String, Vec<usize>)> {
     }
     s.push(("global_avg_pool.1.weight".to_string(), vec![pl, ic, 1, 1]));
     bn(&mut s, "global_avg_pool.2", pl);
-    s.push(("conv1.weight".to_string(), vec![ic, 5 * pl, 1, 1]));
-    bn(&mut s, "bn1", ic);
+    s.push(("conv1.weight".to_string(), vec![oc, 5 * pl, 1, 1]));
+    bn(&mut s, "bn1", oc);
     s
+}
+/// the module `BasicDecBlk` builds: `ASPPDeformable::new(64, None, vb)` (decoder.rs:107-111)
+pub fn aspp_weight_spec() -> Vec<(String, Vec<usize>)> {
+    aspp_weight_spec_for(64, 64)
 }
 
 /// ASPP with deformable convolutions (aspp.rs:227).  `mode`: `BRN_DEFORM_REFERENCE_CPU` = what the reference's CPU path computes
 /// (aspp.rs:183-185), `BRN_DEFORM_DEFORMABLE` = the Metal path (aspp.rs:58-165).
 pub struct ASPPDeformable {
     named: ffi::NamedTensors,
+    in_channels: usize,
+    out_channels: usize,
     pub mode: i32,
 }
 
 impl ASPPDeformable {
-    /// aspp.rs:237 — same signature; the HIP backend covers the configuration the model uses: in_channels 64, out_channels None / 64
+    /// aspp.rs:237 — same signature, any widths (`out_channels` None = `in_channels`, aspp.rs:242)
     pub fn new(in_channels: usize, out_channels: Option<usize>, vb: VarBuilder) -> Result<Self> {
-        if in_channels != 64 || out_channels.unwrap_or(in_channels) != 64 {
-            candle_core::bail!("ASPPDeformable (hip): 64 -> 64 channels only (the module BasicDecBlk builds, decoder.rs:107-111)")
-        }
-        Ok(Self { named: ffi::NamedTensors::from_varbuilder(&vb, &aspp_weight_spec())?, mode: ffi::BRN_DEFORM_REFERENCE_CPU })
+        let out_channels = out_channels.unwrap_or(in_channels);
+        let named = ffi::NamedTensors::from_varbuilder(&vb, &aspp_weight_spec_for(in_channels, out_channels))?;
+        Ok(Self { named, in_channels, out_channels, mode: ffi::BRN_DEFORM_REFERENCE_CPU })
     }
 }
 
 impl Module for ASPPDeformable {
-    /// aspp.rs:303 — x [B,64,H,W] -> [B,64,H,W]
+    /// aspp.rs:303 — x [B,in_channels,H,W] -> [B,out_channels,H,W]
     fn forward(&self, x: &Tensor) -> Result<Tensor> {
         let (b, c, h, w) = x.dims4()?;
-        if c != 64 {
-            candle_core::bail!("expected 64 input channels, got {c}")
+        if c != self.in_channels {
+            candle_core::bail!("expected {} input channels, got {c}", self.in_channels)
         }
         let xin = ffi::to_host(x)?;
-        let mut out = vec![0f32; b * 64 * h * w];
+        let mut out = vec![0f32; b * self.out_channels * h * w];
         let prefix = std::ffi::CString::new("").unwrap();
         ffi::check(unsafe {
-            ffi::brn_aspp_deformable_forward(self.named.views.as_ptr(), self.named.views.len(), prefix.as_ptr(), self.mode, xin.as_ptr(), b as i32,
-                                             h as i32, w as i32, out.as_mut_ptr(), ffi::BRN_MEM_HOST, 0, std::ptr::null_mut())
+            ffi::brn_aspp_deformable_forward(self.named.views.as_ptr(), self.named.views.len(), prefix.as_ptr(), self.in_channels as i32,
+                                             self.out_channels as i32, self.mode, xin.as_ptr(), b as i32, h as i32, w as i32, out.as_mut_ptr(),
+                                             ffi::BRN_MEM_HOST, 0, std::ptr::null_mut())
         })?;
-        Tensor::from_vec(out, (b, 64, h, w), x.device())
+        Tensor::from_vec(out, (b, self.out_channels, h, w), x.device())
     }
 }

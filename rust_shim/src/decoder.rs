@@ -167,7 +167,7 @@ impl Module for BasicLatBlk {
 /// every tensor `BasicDecBlk::new(in_channels, out_channels, config, vb)` asks its VarBuilder for (decoder.rs:104-114), names
 /// relative to `vb`
 pub fn decblk_weight_spec(in_channels: usize, out_channels: usize, config: &DecoderConfig) -> Vec<(String, Vec<usize>)> {
-    let ic = 64usize;
+    let ic = if config.inter_channels_adaptive { in_channels / 4 } else { 64usize };   // decoder.rs:94-98
     let mut s: Vec<(String, Vec<usize>)> = Vec::new();
     let bn = |s: &mut Vec<(String, Vec<usize>)>, p: &str, c: usize| {
         for leaf in ["weight", "bias", "running_mean", "running_var"] {
@@ -178,7 +178,7 @@ pub fn decblk_weight_spec(in_channels: usize, out_channels: usize, config: &Deco
     s.push(("conv_in.bias".to_string(), vec![ic]));
     bn(&mut s, "bn_in", ic);
     if config.use_aspp_deformable {
-        for (name, shape) in crate::aspp::aspp_weight_spec() {
+        for (name, shape) in crate::aspp::aspp_weight_spec_for(ic, ic) {
             s.push((format!("dec_att.{name}"), shape));
         }
     }
@@ -195,20 +195,18 @@ pub struct BasicDecBlk {
     named: ffi::NamedTensors,
     pub in_channels: usize,
     pub out_channels: usize,
+    pub inter_channels: usize,
     pub use_aspp_deformable: bool,
     /// `BRN_DEFORM_REFERENCE_CPU` (what the reference's CPU path computes, aspp.rs:183-185) or `BRN_DEFORM_DEFORMABLE` (aspp.rs:58-165)
     pub mode: i32,
 }
 
 impl BasicDecBlk {
-    /// decoder.rs:87-123 — same signature.  `inter_channels_adaptive` (in_channels / 4 intermediate channels) is not what BiRefNet
-    /// builds (decoder.rs:21) and is not covered by the HIP backend.
+    /// decoder.rs:87-123 — same signature (inter_channels = 64, or in_channels / 4 with `inter_channels_adaptive`, decoder.rs:94-98)
     pub fn new(in_channels: usize, out_channels: usize, config: &DecoderConfig, vb: VarBuilder) -> Result<Self> {
-        if config.inter_channels_adaptive {
-            candle_core::bail!("BasicDecBlk (hip): inter_channels_adaptive is not supported (BiRefNet uses the fixed 64, decoder.rs:21)")
-        }
+        let inter_channels = if config.inter_channels_adaptive { in_channels / 4 } else { 64 };
         let named = ffi::NamedTensors::from_varbuilder(&vb, &decblk_weight_spec(in_channels, out_channels, config))?;
-        Ok(Self { named, in_channels, out_channels, use_aspp_deformable: config.use_aspp_deformable, mode: ffi::BRN_DEFORM_REFERENCE_CPU })
+        Ok(Self { named, in_channels, out_channels, inter_channels, use_aspp_deformable: config.use_aspp_deformable, mode: ffi::BRN_DEFORM_REFERENCE_CPU })
     }
 }
 
@@ -224,7 +222,7 @@ impl Module for BasicDecBlk {
         let prefix = std::ffi::CString::new("").unwrap();
         ffi::check(unsafe {
             ffi::brn_decblk_forward(self.named.views.as_ptr(), self.named.views.len(), prefix.as_ptr(), self.in_channels as i32,
-                                    self.out_channels as i32, self.use_aspp_deformable as i32, self.mode, xin.as_ptr(), b as i32, h as i32,
+                                    self.out_channels as i32, self.inter_channels as i32, self.use_aspp_deformable as i32, self.mode, xin.as_ptr(), b as i32, h as i32,
                                     w as i32, out.as_mut_ptr(), ffi::BRN_MEM_HOST, 0, std::ptr::null_mut())
         })?;
         Tensor::from_vec(out, (b, self.out_channels, h, w), x.device())

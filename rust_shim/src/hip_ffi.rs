@@ -121,10 +121,11 @@ extern "C" {
                                      offset_b: *const c_float, mod_w: *const c_float, mod_b: *const c_float, wgt: *const c_float,
                                      bias: *const c_float, o: c_int, k: c_int, stride: c_int, pad: c_int, mode: c_int, y: *mut c_float,
                                      loc: c_int, device_ordinal: c_int, stream: *mut c_void) -> c_int;
-    pub fn brn_aspp_deformable_forward(weights: *const BrnNamedTensor, n_weights: usize, prefix: *const c_char, mode: c_int, x: *const c_float,
-                                       b: c_int, h: c_int, w: c_int, y: *mut c_float, loc: c_int, device_ordinal: c_int, stream: *mut c_void) -> c_int;
+    pub fn brn_aspp_deformable_forward(weights: *const BrnNamedTensor, n_weights: usize, prefix: *const c_char, in_channels: c_int,
+                                       out_channels: c_int, mode: c_int, x: *const c_float, b: c_int, h: c_int, w: c_int, y: *mut c_float,
+                                       loc: c_int, device_ordinal: c_int, stream: *mut c_void) -> c_int;
     pub fn brn_decblk_forward(weights: *const BrnNamedTensor, n_weights: usize, prefix: *const c_char, in_channels: c_int, out_channels: c_int,
-                              use_aspp: c_int, mode: c_int, x: *const c_float, b: c_int, h: c_int, w: c_int, y: *mut c_float, loc: c_int,
+                              inter_channels: c_int, use_aspp: c_int, mode: c_int, x: *const c_float, b: c_int, h: c_int, w: c_int, y: *mut c_float, loc: c_int,
                               device_ordinal: c_int, stream: *mut c_void) -> c_int;
     pub fn brn_preprocess_image(pixels: *const c_uchar, h: c_int, w: c_int, channels: c_int, s: c_int, x_nchw_out: *mut c_float,
                                 out_loc: c_int, device_ordinal: c_int, stream: *mut c_void) -> c_int;

@@ -556,7 +556,7 @@ def test_deform_conv2d_bf16_kernel_versions_bit_equal(gpu, tmp_path):
         "         'regular_conv.weight': rnd(O, C, k, k, seed=5, std=(C * k * k) ** -0.5), 'regular_conv.bias': rnd(O, seed=6, std=0.1)}\n"
         "    layer = cb.DeformableConv2d.new(C, O, k, stride, pad, cb.VarBuilder.from_tensors(t), mode='deformable')\n"
         "    ops.set_compute('bf16')\n"
-        "    outs[str(i)] = np.asarray(layer.forward(rnd(B, C, H, H + (i % 3), seed=9)))\n"
+        "    outs[str(i)] = np.asarray(layer.forward(rnd(B, C, H, H + (i %% 3), seed=9)))\n"
         "    ops.set_compute('f32')\n"
         "np.savez(sys.argv[1], **outs)\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
     res = {}
@@ -618,3 +618,92 @@ def test_linear_residual_layer_norm_fp32_modes(gpu):
             ops.set_compute("f32")
         _close(xo, xr, tol=3e-5 if mode != "f32_split2" else 2e-4)
         _close(yo, yr, tol=3e-5 if mode != "f32_split2" else 2e-4)
+
+
+@pytest.mark.parametrize("ic,oc,H,W,mode,compute", [
+    (64, None, 12, 12, "deformable", "f32"),                 # what BasicDecBlk builds
+    (128, None, 10, 14, "reference_cpu", "f32_split3"),       # wider, out_channels None = in_channels (aspp.rs:242)
+    (48, 80, 12, 9, "deformable", "f32"),                    # in_channels off the channel granule, out_channels != in_channels
+    (96, 32, 16, 16, "deformable", "f32_split2"),
+    (20, 24, 8, 8, "reference_cpu", "f32"),
+])
+def test_aspp_deformable_any_width_vs_oracle(gpu, ic, oc, H, W, mode, compute):
+    """ASPPDeformable::new(in_channels, out_channels, vb) for widths other than the 64 -> 64 of BasicDecBlk (aspp.rs:236-246 takes any
+    in_channels / out_channels): brn_aspp_deformable_forward against the oracle's restatement, at the north-star gate."""
+    from candle_birefnet_amd import ops
+    from candle_birefnet_amd.weights import _aspp, synth_weights
+    from oracle import oracle as O
+    w = synth_weights(_aspp("", ic, oc), seed=11)
+    x = rnd(2, ic, H, W, seed=5)
+    ops.set_compute(compute)
+    try:
+        y = ops.aspp_deformable(x, w, mode, out_channels=oc)
+    finally:
+        ops.set_compute("f32")
+    ref = O.aspp_deformable(x, w, 1 if mode == "deformable" else 0, out_channels=oc).astype(np.float64)
+    assert y.shape == ref.shape == (2, oc or ic, H, W)
+    err = np.abs(np.asarray(y, np.float64) - ref)
+    assert ((err <= 1e-3) | (err <= 1e-2 * np.abs(ref))).all(), f"max abs err {err.max():.3e}"
+    assert err.max() <= 2e-4 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("mode", ["reference_cpu", "deformable"])
+def test_aspp_deformable_any_width_bf16_mode(gpu, mode):
+    """the same in compute mode bf16 (maps padded to 64-channel chunks inside): bounded against the oracle"""
+    from candle_birefnet_amd import ops
+    from candle_birefnet_amd.weights import _aspp, synth_weights
+    from oracle import oracle as O
+    for ic, oc in ((128, None), (48, 80)):
+        w = synth_weights(_aspp("", ic, oc), seed=12)
+        x = rnd(1, ic, 16, 16, seed=6)
+        ops.set_compute("bf16")
+        try:
+            y = ops.aspp_deformable(x, w, mode, out_channels=oc)
+        finally:
+            ops.set_compute("f32")
+        ref = O.aspp_deformable(x, w, 1 if mode == "deformable" else 0, out_channels=oc).astype(np.float64)
+        err = np.abs(np.asarray(y, np.float64) - ref).max()
+        print(f"ASPP bf16 {ic}->{oc or ic} {mode}: max abs err {err:.2e}, |ref| max {np.abs(ref).max():.2f}")
+        assert err <= 3e-2 * max(1.0, np.abs(ref).max())
+
+
+def test_decblk_inter_channels_adaptive_vs_oracle(gpu):
+    """DecoderConfig { inter_channels_adaptive: true }: inter_channels = in_channels / 4 (decoder.rs:94-98) — 96 and 40 here, the second
+    off the channel granule (the maps between the convs are padded) — with and without the ASPP"""
+    from candle_birefnet_amd import ops
+    from candle_birefnet_amd.weights import _decblk, synth_weights
+    from oracle import oracle as O
+    for cin, cout, use_aspp, mode in ((384, 96, True, "deformable"), (160, 64, True, "reference_cpu"), (160, 72, False, "reference_cpu")):
+        w = synth_weights(_decblk("", cin, cout, inter=cin // 4, use_aspp=use_aspp), seed=13)
+        x = rnd(1, cin, 12, 16, seed=7)
+        y = ops.decblk(x, w, cout, mode=mode, use_aspp=use_aspp, inter_channels_adaptive=True)
+        ref = O.decblk(x, w, cout, mode=1 if mode == "deformable" else 0, use_aspp=use_aspp, inter_channels_adaptive=True).astype(np.float64)
+        err = np.abs(np.asarray(y, np.float64) - ref)
+        assert ((err <= 1e-3) | (err <= 1e-2 * np.abs(ref))).all(), f"{cin}->{cout}: max abs err {err.max():.3e}"
+
+
+@pytest.mark.parametrize("C,O,k,stride,compute", [(20, 24, 3, 1, "f32"), (100, 64, 3, 2, "f32_split3"), (48, 40, 1, 1, "bf16"), (72, 32, 7, 1, "bf16")])
+def test_deformable_conv2d_any_in_channels(gpu, C, O, k, stride, compute):
+    """DeformableConv2d::new(in_channels, ..) takes any in_channels in the reference (deform_conv.rs:29-36); the deformable mode used to
+    need a multiple of 32: the map is now padded with zero channels inside.  Against the oracle (bf16: bounded)."""
+    import candle_birefnet_amd as cb
+    from candle_birefnet_amd import ops
+    from oracle import oracle as O
+    pad = k // 2
+    t = {"offset_conv.weight": rnd(2 * k * k, C, k, k, seed=1, std=1.5 * (C * k * k) ** -0.5), "offset_conv.bias": rnd(2 * k * k, seed=2, std=0.3),
+         "modulator_conv.weight": rnd(k * k, C, k, k, seed=3, std=(C * k * k) ** -0.5), "modulator_conv.bias": rnd(k * k, seed=4, std=0.1),
+         "regular_conv.weight": rnd(O, C, k, k, seed=5, std=(C * k * k) ** -0.5), "regular_conv.bias": rnd(O, seed=6, std=0.1)}
+    layer = cb.DeformableConv2d.new(C, O, k, stride, pad, cb.VarBuilder.from_tensors(t), mode="deformable")
+    x = rnd(2, C, 13, 11, seed=9)
+    ops.set_compute(compute)
+    try:
+        y = layer.forward(x)
+    finally:
+        ops.set_compute("f32")
+    ref = O.deform_conv2d(x, t["offset_conv.weight"], t["offset_conv.bias"], t["modulator_conv.weight"], t["modulator_conv.bias"],
+                          t["regular_conv.weight"], t["regular_conv.bias"], k, stride, pad, 1).astype(np.float64)
+    err = np.abs(np.asarray(y, np.float64) - ref)
+    if compute == "bf16":
+        assert err.max() <= 3e-2 * max(1.0, np.abs(ref).max())
+    else:
+        assert ((err <= 1e-3) | (err <= 1e-2 * np.abs(ref))).all(), f"max abs err {err.max():.3e}"
