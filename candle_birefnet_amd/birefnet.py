@@ -216,12 +216,17 @@ def _stage_dims(H, W, patch):
 class SwinTransformer:
     """swin.rs:718-797: SwinTransformer::new(config, vb) / forward(x) -> [x1, x2, x3, x4] (NCHW)."""
 
-    def __init__(self, config: SwinConfig, vb: VarBuilder, device: int = 0):
+    def __init__(self, config: SwinConfig, vb: VarBuilder, device: int = 0, compute: str = "f32"):
         self.config = config
+        self.compute = compute
         self._h = C.c_void_p()
         arr, keep = _named_array(vb.tensors_under_prefix())
         cfg = swin_to_c(config)
-        _ffi.check(_ffi.lib.brn_swin_create(C.byref(cfg), arr, len(arr), b"", device, C.byref(self._h)))
+        _ffi.check(_ffi.lib.brn_set_op_compute(BiRefNet.COMPUTE[compute]))     # the handle is built for the calling thread's op arithmetic
+        try:
+            _ffi.check(_ffi.lib.brn_swin_create(C.byref(cfg), arr, len(arr), b"", device, C.byref(self._h)))
+        finally:
+            _ffi.check(_ffi.lib.brn_set_op_compute(_ffi.BRN_F32))
         del keep
 
     @staticmethod

@@ -333,7 +333,7 @@ static void run_model_locked(Model* m, const float* x, int B, int H, int W, brn_
 using namespace brn;
 
 struct brn_model { Model m; };
-struct brn_swin { brn_config cfg; int device; DeviceOwner own; SwinW w; std::mutex mu; };
+struct brn_swin { brn_config cfg; int device; DeviceOwner own; SwinW w; std::mutex mu; bool bf16 = false; };
 
 extern "C" {
 
@@ -703,35 +703,6 @@ brn_status brn_postprocess_mask(const float* logits, int S, brn_mem in_loc, int 
     });
 }
 
-// ---- stand-alone SwinTransformer -----------------------------------------------------------------------------------------
-brn_status brn_swin_create(const brn_config* cfg, const brn_named_tensor* weights, size_t n, const char* prefix, int device,
-                           brn_swin** out) {
-    return guarded([&] {
-        if (!cfg || !weights || !out) fail(BRN_ERR_INVALID_ARG, "null argument");
-        *out = nullptr;
-        ensure_device(device);
-        std::unique_ptr<brn_swin> h(new brn_swin());
-        h->cfg = *cfg; h->device = device;
-        WeightTable wt(weights, n);
-        build_swin_weights(wt, prefix ? prefix : "", *cfg, h->own, h->w);
-        *out = h.release();
-    });
-}
-void brn_swin_destroy(brn_swin* s) {
-    if (!s) return;
-    (void)hipSetDevice(s->device);
-    (void)hipDeviceSynchronize();
-    delete s;
-}
-brn_status brn_swin_forward(brn_swin* s, const float* x, int B, int H, int W, brn_mem in_loc, float* const outs[4],
-                            brn_mem out_loc, void* stream) {
-    return guarded([&] {
-        if (!s) fail(BRN_ERR_INVALID_ARG, "null handle");
-        std::lock_guard<std::mutex> lk(s->mu);
-        swin_entry(s->w, s->device, x, B, H, W, in_loc, outs, out_loc, stream);
-    });
-}
-
 // ---- op-level entry points (weights are always host pointers; x / y / residual follow `loc`) -------------------------------------
 static thread_local int g_op_planes = 0;
 brn_status brn_set_op_compute(int dtype) {
@@ -749,6 +720,38 @@ brn_status brn_set_op_compute(int dtype) {
     });
 }
 struct OpPlanes { OpPlanes() { set_build_planes(g_op_planes); } ~OpPlanes() { set_build_planes(0); } };
+
+// ---- stand-alone SwinTransformer -----------------------------------------------------------------------------------------
+brn_status brn_swin_create(const brn_config* cfg, const brn_named_tensor* weights, size_t n, const char* prefix, int device,
+                           brn_swin** out) {
+    return guarded([&] {
+        if (!cfg || !weights || !out) fail(BRN_ERR_INVALID_ARG, "null argument");
+        *out = nullptr;
+        ensure_device(device);
+        std::unique_ptr<brn_swin> h(new brn_swin());
+        h->cfg = *cfg; h->device = device;
+        WeightTable wt(weights, n);
+        OpPlanes op_planes;                    // the arithmetic brn_set_op_compute selected on this thread (default BRN_F32)
+        h->bf16 = g_op_planes == BUILD_BF16;
+        build_swin_weights(wt, prefix ? prefix : "", *cfg, h->own, h->w);
+        *out = h.release();
+    });
+}
+void brn_swin_destroy(brn_swin* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    (void)hipDeviceSynchronize();
+    delete s;
+}
+brn_status brn_swin_forward(brn_swin* s, const float* x, int B, int H, int W, brn_mem in_loc, float* const outs[4],
+                            brn_mem out_loc, void* stream) {
+    return guarded([&] {
+        if (!s) fail(BRN_ERR_INVALID_ARG, "null handle");
+        std::lock_guard<std::mutex> lk(s->mu);
+        swin_entry(s->w, s->device, x, B, H, W, in_loc, outs, out_loc, stream, s->bf16);
+    });
+}
+
 
 brn_status brn_linear_forward(const float* x, int M, int K, const float* w, const float* bias, int N, int act,
                               const float* residual, float* y, brn_mem loc, int device, void* stream) {
@@ -893,7 +896,6 @@ brn_status brn_window_attention_forward(const float* x, int B, int H, int W, int
         if (!x || !qkv_w || !qkv_b || !proj_w || !proj_b || !rel_table || !y) fail(BRN_ERR_INVALID_ARG, "null argument");
         if (!(window_size == 12 || window_size == 7) || heads < 1 || C != heads * 32 || !(shift == 0 || shift == window_size / 2))
             fail(BRN_ERR_INVALID_ARG, "window attention needs window_size 12 or 7, head_dim 32, shift 0 or window_size / 2");
-        if (window_size == 7 && g_op_planes != 0) fail(BRN_ERR_INVALID_ARG, "window_size 7 runs in compute mode f32 only");
         ensure_device(device);
         DeviceOwner own;
         // reuse the model's weight builder through a one-block table

@@ -43,7 +43,27 @@ constexpr int ATT_THREADS = 192;   // 3 waves, 3 query tiles each
 // NWV = waves per workgroup: 3 (three query tiles each at window 12) or 9 (one query tile each: the workgroup lives a third as long on
 // the same 41.5 KB of LDS = 3 workgroups per CU; at batch 1 a stage-2 launch is 1080 workgroups on 768 slots = two rounds whatever
 // the wave count, so the round time is what counts)
-template <int WSZ, int NWV = 3>
+// IOB = the qkv matrix and the output are bf16 (compute mode BRN_BF16 with a window the bf16 kernel below is not built for: window 7 of
+// Swin-T / S): operands are widened on load — a pad token's q / k / v is the qkv bias rounded to bf16, what the qkv GEMM of that mode would
+// have stored — the arithmetic stays the exact fp32 MFMA chain, the result is rounded once on store.
+template <bool IOB>
+__device__ __forceinline__ f32x4 att_load4(const float* base, long off) {
+    if constexpr (IOB) {
+        typedef __bf16 bf16x4_ld __attribute__((ext_vector_type(4)));
+        const bf16x4_ld h = *reinterpret_cast<const bf16x4_ld*>(reinterpret_cast<const __bf16*>(base) + off);
+        return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    } else return *reinterpret_cast<const f32x4*>(base + off);
+}
+template <bool IOB>
+__device__ __forceinline__ f32x4 att_bias4(const float* bias) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(bias);
+    if constexpr (IOB) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (float)(__bf16)v[e];
+    }
+    return v;
+}
+template <int WSZ, int NWV = 3, bool IOB = false>
 __global__ void __launch_bounds__(NWV * 64) window_attention_f32_kernel(const WindowAttnParams pa, const WindowAttnParams pb, const int nblk0) {
     constexpr int WS = WSZ, NTOK = WSZ * WSZ, NT16 = (NTOK + 15) / 16, NPADTOK = NT16 * 16;
     constexpr int NTHR = NWV * 64;
@@ -89,9 +109,9 @@ __global__ void __launch_bounds__(NWV * 64) window_attention_f32_kernel(const Wi
     for (int idx = tid; idx < NPADTOK * 8; idx += NTHR) {
         const int t = idx >> 3, c4 = (idx & 7) * 4;
         const int src = src_s[t];
-        const float* kp = src >= 0 ? p.qkv + (long)src * C3 + C + head * HD + c4 : p.qkv_bias + C + head * HD + c4;
-        f32x4 kv = *reinterpret_cast<const f32x4*>(kp);
-        f32x4 vv = *reinterpret_cast<const f32x4*>(kp + C);
+        f32x4 kv, vv;
+        if (src >= 0) { kv = att_load4<IOB>(p.qkv, (long)src * C3 + C + head * HD + c4); vv = att_load4<IOB>(p.qkv, (long)src * C3 + 2 * C + head * HD + c4); }
+        else { kv = att_bias4<IOB>(p.qkv_bias + C + head * HD + c4); vv = att_bias4<IOB>(p.qkv_bias + 2 * C + head * HD + c4); }
         if (t >= NTOK) { kv = f32x4{0.f, 0.f, 0.f, 0.f}; vv = kv; }      // dummy tail of the last tile
         *reinterpret_cast<f32x4*>(Ks + t * KV_LD + c4) = kv;
         *reinterpret_cast<f32x4*>(Vs + t * KV_LD + c4) = vv;
@@ -104,9 +124,8 @@ __global__ void __launch_bounds__(NWV * 64) window_attention_f32_kernel(const Wi
     // cost occupancy and was slower)
     auto load_q = [&](int qt, f32x4& q0, f32x4& q1) {
         const int qs = src_s[qt * 16 + li];
-        const float* qp = qs >= 0 ? p.qkv + (long)qs * C3 + head * HD + g * 8 : p.qkv_bias + head * HD + g * 8;
-        q0 = *reinterpret_cast<const f32x4*>(qp);
-        q1 = *reinterpret_cast<const f32x4*>(qp + 4);
+        if (qs >= 0) { q0 = att_load4<IOB>(p.qkv, (long)qs * C3 + head * HD + g * 8); q1 = att_load4<IOB>(p.qkv, (long)qs * C3 + head * HD + g * 8 + 4); }
+        else { q0 = att_bias4<IOB>(p.qkv_bias + head * HD + g * 8); q1 = att_bias4<IOB>(p.qkv_bias + head * HD + g * 8 + 4); }
     };
     f32x4 qn0 = {0.f, 0.f, 0.f, 0.f}, qn1 = qn0;
     if (wave < NT16) load_q(wave, qn0, qn1);
@@ -205,6 +224,14 @@ __global__ void __launch_bounds__(NWV * 64) window_attention_f32_kernel(const Wi
                 float* orow = p.out + (long)qsrc * (C + C / 2);
                 store_planes<3>(orow, head * HD + g * 4, o0 * inv);
                 store_planes<3>(orow, head * HD + 16 + g * 4, o1 * inv);
+            } else if constexpr (IOB) {
+                typedef __bf16 bf16x4_st __attribute__((ext_vector_type(4)));
+                __bf16* op = reinterpret_cast<__bf16*>(p.out) + (long)qsrc * C + head * HD + g * 4;
+                bf16x4_st h0, h1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { h0[e] = (__bf16)(o0[e] * inv); h1[e] = (__bf16)(o1[e] * inv); }
+                *reinterpret_cast<bf16x4_st*>(op) = h0;
+                *reinterpret_cast<bf16x4_st*>(op + 16) = h1;
             } else {
                 float* op = p.out + (long)qsrc * C + head * HD + g * 4;
                 *reinterpret_cast<f32x4*>(op) = o0 * inv;
@@ -674,7 +701,7 @@ static hipError_t check_attention(const WindowAttnParams& p) {
     if (!(ws == 12 || ws == 7)) return hipErrorInvalidValue;
     if (p.C != p.heads * HD || p.Hp % ws || p.Wp % ws || p.Hp < p.H || p.Wp < p.W) return hipErrorInvalidValue;
     if (!(p.shift == 0 || p.shift == ws / 2)) return hipErrorInvalidValue;
-    if (ws != WS && (p.planes || p.out_planes || p.io_bf16)) return hipErrorInvalidValue;   // window 7 (Swin-T / S): the fp32 kernel only
+    if (ws != WS && (p.planes || p.out_planes)) return hipErrorInvalidValue;   // window 7 (Swin-T / S): the fp32-MFMA kernel (fp32 or bf16 matrices in / out)
     return hipSuccess;
 }
 hipError_t launch_window_attention2(const WindowAttnParams& p, const WindowAttnParams* p2, hipStream_t s) {
@@ -690,7 +717,10 @@ hipError_t launch_window_attention2(const WindowAttnParams& p, const WindowAttnP
     if (p.out_planes && !((p.out_planes == 2 && p.planes == 2) || (p.out_planes == 3 && p.planes == 0))) return hipErrorInvalidValue;
     const WindowAttnParams& q = p2 ? *p2 : p;
     dim3 grid(n0 + n1, p.heads), block(ATT_THREADS);
-    if (p.io_bf16) {
+    if (p.io_bf16 && ws == 7) {
+        if (p.out_planes || (p.C & 3)) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((window_attention_f32_kernel<7, 3, true>), grid, block, 0, s, p, q, n0);
+    } else if (p.io_bf16) {
         if (p.out_planes || (p.C & 7)) return hipErrorInvalidValue;
         // (round 2, one stream: two heads per workgroup measured 1 % slower end to end, 224.5 vs 226.8 img/s at batch 8)
         // round 3: two heads per workgroup is the default — alone the launch is 6 % slower (3.25 against 3.05 ms per 8-image step), but it reads

@@ -174,6 +174,9 @@ brn_status brn_model_last_kernel_stats(brn_model* m, int n, int* launches, float
 const char* brn_kernel_family_name(int f);
 
 /* ---- stand-alone SwinTransformer: SwinTransformer::new / forward (swin.rs:725-797) -------------------- */
+/* Any SwinConfig (swin_t / swin_s / swin_b / swin_l: window 7 or 12) and any input size.  The handle is built for the arithmetic that
+ * brn_set_op_compute selected on the creating thread (default BRN_F32): window 12 uses the mode's own attention kernel, window 7 the
+ * fp32-MFMA attention kernel in every mode (on bf16 matrices in mode BRN_BF16). */
 brn_status brn_swin_create(const brn_config* cfg /* swin_* fields */, const brn_named_tensor* weights,
                            size_t n_weights, const char* prefix, int device_ordinal, brn_swin** out);
 void brn_swin_destroy(brn_swin* s);
