@@ -810,7 +810,7 @@ brn_status brn_linear_residual_layer_norm_forward(const float* x, int M, int K, 
             }
             // the residual stream is updated in place inside the model: here x_out starts as a copy of the residual
             if (!c.dry) BRN_HIP(hipMemcpyAsync(dxo, dr, (size_t)M * N * sizeof(float), hipMemcpyDeviceToDevice, c.stream));
-            if (!linear_residual_ln(c, g, a, M, K, dxo, ln, yb, N)) {
+            if (!linear_residual_ln(c, g, a, M, K, dxo, ln, yb, N, true)) {
                 run_gemm(c, g, a, M, K, dxo, N, 0, dxo, N, 0, nullptr, 0, 0, 0, bf ? 1 : 0, bf ? 1 : 0);
                 run_layernorm(c, ln, dxo, M, N, yb, N, 0, 0, bf ? 1 : 0);
             }

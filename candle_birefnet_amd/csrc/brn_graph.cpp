@@ -308,13 +308,16 @@ void swin_stage_dims(int H, int W, int patch, int hs[4], int ws[4]) {
 // proj + residual + the block's second LayerNorm in one launch (compute mode BRN_BF16: gemm_wstat_ln_bf16_kernel for C = 192, M >= 32768;
 // gemm_rowln_bf16_kernel for C = 768 / 384, M >= 4096);
 // false = not applicable, nothing enqueued (no workspace is involved either way, so a dry run and a real run agree trivially)
-bool linear_residual_ln(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* x, const LNW& ln, float* y, int ldy);
 static bool run_gemm_ln(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* x, const LNW& ln, float* y, int ldy) {
-    return linear_residual_ln(c, w, A, M, lda, x, ln, y, ldy);
+    return linear_residual_ln(c, w, A, M, lda, x, ln, y, ldy, false);
 }
-bool linear_residual_ln(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* x, const LNW& ln, float* y, int ldy) {
+bool linear_residual_ln(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* x, const LNW& ln, float* y, int ldy, bool every_fused_kernel) {
     static const bool off = getenv("BRN_WSTAT_LN") && atoi(getenv("BRN_WSTAT_LN")) == 0;
-    static const int rowln_mask = getenv("BRN_ROWLN") ? atoi(getenv("BRN_ROWLN")) : 1;     // bit 0: N = 768 (stage 2), bit 1: N = 384 (stage 1)
+    // gemm_rowln_bf16_kernel (N = 768 / 384) is built and tested but NOT used by the model by default: it streams the whole W through LDS per
+    // 64 rows, and that L2 -> LDS intake costs what the saved fp32 re-read of x is worth (measured at c3: 159 us per stage-2 launch against
+    // 96 + 36 us for projection + LayerNorm; -0.6 % end to end).  BRN_ROWLN: bit 0 = N 768, bit 1 = N 384.
+    static const int rowln_env = getenv("BRN_ROWLN") ? atoi(getenv("BRN_ROWLN")) : 0;
+    const int rowln_mask = every_fused_kernel ? 3 : rowln_env;
     if (!c.bf16 || w.mode != GEMM_DENSE || ln.C != w.N || !ln.g || !ln.b) return false;
     GemmParams p{};
     p.A = A; p.C = x; p.M = M; p.N = w.N; p.K = w.K; p.mode = GEMM_DENSE; p.lda = lda;

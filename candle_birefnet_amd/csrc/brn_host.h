@@ -251,7 +251,8 @@ void run_layernorm(Ctx& c, const LNW& ln, const float* x, int rows, int ldx, flo
 void run_resize(Ctx& c, const Map& in, const Map& out, bool accumulate = false);
 // compute mode BRN_BF16: x = A W^T + bias + x (fp32, in place) and y = LayerNorm(x) as a bf16 matrix in ONE launch where a row-owning
 // kernel covers the shape (N = 192: gemm_wstat_ln_bf16_kernel; N = 768 / 384: gemm_rowln_bf16_kernel); false = nothing enqueued
-bool linear_residual_ln(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* x, const LNW& ln, float* y, int ldy);
+// every_fused_kernel: also the kernels the model does not use by default (the op-level entry point exercises them all)
+bool linear_residual_ln(Ctx& c, const GemmW& w, const float* A, int M, int lda, float* x, const LNW& ln, float* y, int ldy, bool every_fused_kernel = false);
 
 // SwinTransformer::forward (swin.rs:768-797): outs[i] are destination windows (stage outputs after norm_i)
 void swin_forward(Ctx& c, const SwinW& w, const float* img_nchw, int B, int H, int W, const Map outs[4]);

@@ -1200,7 +1200,8 @@ static hipError_t launch_bf16_cfg(const GemmParams& p, hipStream_t s) {
     if (p.mode == GEMM_DENSE) {
         if (epi == 0) BRN_BF16_LAUNCH(GEMM_DENSE, 0); else if (epi == 1) BRN_BF16_LAUNCH(GEMM_DENSE, 1); else BRN_BF16_LAUNCH(GEMM_DENSE, 2);
     } else if (p.mode == GEMM_CONV_NHWC) {
-        if (epi == 0) BRN_BF16_LAUNCH(GEMM_CONV_NHWC, 0); else BRN_BF16_LAUNCH(GEMM_CONV_NHWC, 2);
+        // (flavour 1 = fp32 out: decoder_block1's conv_out, whose result p1 stays fp32 in mode bf16 — brn_graph.cpp, decoder_forward)
+        if (epi == 0) BRN_BF16_LAUNCH(GEMM_CONV_NHWC, 0); else if (epi == 1 && !p.R) BRN_BF16_LAUNCH(GEMM_CONV_NHWC, 1); else BRN_BF16_LAUNCH(GEMM_CONV_NHWC, 2);
     } else return hipErrorInvalidValue;
 #undef BRN_BF16_LAUNCH
     return hipGetLastError();

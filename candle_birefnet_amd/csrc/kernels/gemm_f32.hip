@@ -657,7 +657,20 @@ template <int MODE, int NP, int KS, bool DIAG, bool APL>   // APL: A arrives in 
 __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) {
     constexpr int BM = 128, BN = 128, WTM = 64, WTN = 64, TM = 2, TN = 2;
     static_assert(!APL || ((NP == 2 || NP == 3) && MODE == GEMM_DENSE), "the P input layout is the NP-plane split of a dense A");
-    constexpr int SLD = KS + 8;                     // bf16 per LDS row (16-byte pad: conflict-free b128 fragment reads)
+    // LDS rows (round 4): UNPADDED KS-element rows with the 16-byte chunks of a row XOR-permuted by the row — key (row >> 3) & 1 for the
+    // 32-byte rows of a 16-deep stage (8 rows per 256-byte bank row), (row >> 2) & 3 for 64-byte rows (4 per bank row).  A ds_read_b128
+    // lane group (16 consecutive rows, one logical chunk) then touches 16 different 16-byte slots, AND a producer store instruction
+    // (8-byte pieces: 4 or 8 lanes per row, 32 lanes = 8 or 4 whole rows) covers one bank row exactly once.  The padded rows this
+    // replaces (KS + 8 elements: 48 / 80 bytes) were conflict-free for the reads only: the producers' ds_write_b64 halves wrapped onto
+    // banks of the first rows (rows 0 / 5, 1 / 6, 2 / 7 of a 32-lane half at 48 bytes) — the 4 % SQ_LDS_BANK_CONFLICT of
+    // profiles/r03_pmc_sq_c2_f32_split3.csv, paid by the staging waves, which are this kernel's critical path.  BRN_WS_SWZ=0 builds the
+    // padded layout (same-box A/B of two libraries: tools/ab_lib.sh).
+#ifndef BRN_WS_SWZ
+#define BRN_WS_SWZ 1
+#endif
+    constexpr bool SWZ = BRN_WS_SWZ != 0;
+    constexpr int SLD = SWZ ? KS : KS + 8;          // bf16 per LDS row
+    auto swz_key = [](int row) { return SWZ ? (KS == 16 ? (row >> 3) & 1 : (row >> 2) & 3) : 0; };
     constexpr int KSTEPS = KS / 16;                 // MFMA k-steps per stage
     constexpr int NBUF = 2;                         // 2 x NP x 20 KB: two workgroups per CU at NP <= 2 (a 3-deep ring was slower: 1 WG/CU exposes each tile's prologue + epilogue)
     constexpr int AQ = KS / 4, RPP = 256 / AQ;                  // producers: 256 threads, AQ float4 per KS-float row
@@ -714,7 +727,7 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
             if (APL) {
                 const int q = i * 256 + pt, row = q / (4 * NP), c = q - row * (4 * NP);   // chunk c of the row: plane c / 4, k = 8 (c % 4)
                 m = m0 + row;
-                p_lds[i] = ((c >> 2) * BM + row) * SLD + (c & 3) * 8;
+                p_lds[i] = ((c >> 2) * BM + row) * SLD + ((c & 3) ^ swz_key(row)) * 8;
             }
             a_ok[i] = m < p.M;
             a_iy[i] = 0; a_ix[i] = 0;
@@ -733,6 +746,9 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
             }
         }
         const int wc = pt % WQ, wrow = pt / WQ;
+        // element offsets inside an LDS row of this thread's pieces (RPP and WRPP are multiples of 32 rows: the key is that of lrow / wrow)
+        const int a_sw = ((kq >> 1) ^ swz_key(lrow)) * 8 + (kq & 1) * 4;
+        const int w_sw = (wc ^ swz_key(wrow)) * 8;
         static_assert(KS == 32 || KS == 16, "the interleaved W plane layout is per 32-deep K tile; a 16-deep stage takes one half of it");
         static_assert(!APL || KS == 32, "P-layout input is staged in whole 32-deep K tiles");
         const long wrow_stride = (long)p.K * NP;         // W planes interleaved per K tile: [row][K/32][plane][32] bf16
@@ -863,14 +879,14 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
                 if (BUFA || (BUFC && bufc_ok)) split4<NP, false>(qa[i], qm[i], sp); else split4<NP>(qa[i], qm[i], sp);
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl)
-                    *reinterpret_cast<bf16x4*>(As + (pl * BM + lrow + i * RPP) * SLD + kq * 4) = sp[pl];
+                    *reinterpret_cast<bf16x4*>(As + (pl * BM + lrow + i * RPP) * SLD + a_sw) = sp[pl];
             }
             }
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
                 for (int i = 0; i < PB; ++i)
-                    *reinterpret_cast<bf16x8*>(Bs + (pl * BN + wrow + i * WRPP) * SLD + wc * 8) = qb[pl][i];
+                    *reinterpret_cast<bf16x8*>(Bs + (pl * BN + wrow + i * WRPP) * SLD + w_sw) = qb[pl][i];
         };
         constexpr int AHEAD = NBUF - 1;     // LDS tiles the producers run ahead of the consumers
         // prologue: LDS tiles 0 .. AHEAD-1 stored, register sets hold the next two tiles
@@ -912,16 +928,20 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int wm = wave >> 1, wn = wave & 1;
-    const int a_off = (wm * WTM + (lane & 31)) * SLD + (lane >> 5) * 8;
-    const int b_off = NP * BM * SLD + (wn * WTN + (lane & 31)) * SLD + (lane >> 5) * 8;
+    // (the swizzle key of a fragment row depends on its low five bits only: every block offset below is a multiple of 32 rows)
+    const int fkey = swz_key(lane & 31);
+    const int a_row = (wm * WTM + (lane & 31)) * SLD, b_row = NP * BM * SLD + (wn * WTN + (lane & 31)) * SLD;
+    int f_chunk[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) f_chunk[ks] = (((lane >> 5) + 2 * ks) ^ fkey) * 8;
     auto read_frags = [&](int t, int ks, bf16x8 (&af)[NP][TM], bf16x8 (&bf)[NP][TN]) {
         const __bf16* buf = smem + (t % NBUF) * BUF;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[pl][i] = *reinterpret_cast<const bf16x8*>(buf + a_off + (pl * BM + i * 32) * SLD + ks * 16);
+            for (int i = 0; i < TM; ++i) af[pl][i] = *reinterpret_cast<const bf16x8*>(buf + a_row + (pl * BM + i * 32) * SLD + f_chunk[ks]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[pl][j] = *reinterpret_cast<const bf16x8*>(buf + b_off + (pl * BN + j * 32) * SLD + ks * 16);
+            for (int j = 0; j < TN; ++j) bf[pl][j] = *reinterpret_cast<const bf16x8*>(buf + b_row + (pl * BN + j * 32) * SLD + f_chunk[ks]);
         }
     };
     auto mfma_all = [&](const bf16x8 (&af)[NP][TM], const bf16x8 (&bf)[NP][TN]) {

@@ -688,7 +688,7 @@ def test_deformable_conv2d_any_in_channels(gpu, C, O, k, stride, compute):
     need a multiple of 32: the map is now padded with zero channels inside.  Against the oracle (bf16: bounded)."""
     import candle_birefnet_amd as cb
     from candle_birefnet_amd import ops
-    from oracle import oracle as O
+    from oracle import oracle as ORC
     pad = k // 2
     t = {"offset_conv.weight": rnd(2 * k * k, C, k, k, seed=1, std=1.5 * (C * k * k) ** -0.5), "offset_conv.bias": rnd(2 * k * k, seed=2, std=0.3),
          "modulator_conv.weight": rnd(k * k, C, k, k, seed=3, std=(C * k * k) ** -0.5), "modulator_conv.bias": rnd(k * k, seed=4, std=0.1),
@@ -700,7 +700,7 @@ def test_deformable_conv2d_any_in_channels(gpu, C, O, k, stride, compute):
         y = layer.forward(x)
     finally:
         ops.set_compute("f32")
-    ref = O.deform_conv2d(x, t["offset_conv.weight"], t["offset_conv.bias"], t["modulator_conv.weight"], t["modulator_conv.bias"],
+    ref = ORC.deform_conv2d(x, t["offset_conv.weight"], t["offset_conv.bias"], t["modulator_conv.weight"], t["modulator_conv.bias"],
                           t["regular_conv.weight"], t["regular_conv.bias"], k, stride, pad, 1).astype(np.float64)
     err = np.abs(np.asarray(y, np.float64) - ref)
     if compute == "bf16":
