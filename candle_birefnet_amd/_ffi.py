@@ -111,6 +111,7 @@ _sig("brn_decblk_forward", C.c_int, _vp, C.c_size_t, C.c_char_p, C.c_int, C.c_in
 
 _sig("brn_preprocess_image", C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp)
 _sig("brn_postprocess_mask", C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp)
+_sig("brn_infer_images_u8", C.c_int, _vp, C.c_int, C.POINTER(_vp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(_vp), _vp)
 _sig("brn_set_op_compute", C.c_int, C.c_int)
 if hasattr(lib, "brn_gemm_microbench"):   # only in libbirefnet_hip_diag.so (make diag; include/birefnet_hip_diag.h), reached through BRN_LIB_PATH
     _sig("brn_gemm_microbench", C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float))
@@ -123,7 +124,7 @@ DECLARED = [
     "brn_model_set_profiling", "brn_model_last_timings", "brn_model_last_kernel_stats", "brn_kernel_family_name",
     "brn_swin_create", "brn_swin_destroy", "brn_swin_forward", "brn_linear_forward", "brn_linear_residual_layer_norm_forward", "brn_layer_norm_forward",
     "brn_conv2d_forward", "brn_upsample_bilinear2d", "brn_window_attention_forward", "brn_patch_merging_forward",
-    "brn_deform_conv2d_forward", "brn_aspp_deformable_forward", "brn_decblk_forward", "brn_set_op_compute", "brn_preprocess_image", "brn_postprocess_mask",
+    "brn_deform_conv2d_forward", "brn_aspp_deformable_forward", "brn_decblk_forward", "brn_set_op_compute", "brn_preprocess_image", "brn_postprocess_mask", "brn_infer_images_u8",
 ]
 
 

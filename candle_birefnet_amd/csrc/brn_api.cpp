@@ -703,6 +703,77 @@ brn_status brn_postprocess_mask(const float* logits, int S, brn_mem in_loc, int 
     });
 }
 
+// examples/infer_image.rs:44-110 for a batch (see the header).  The staging pool: [raw images | vertical-pass temporaries (pre) |
+// x batch | mask probabilities | u8 masks at S | vertical-pass temporaries (post) | u8 masks at the images' sizes]
+brn_status brn_infer_images_u8(brn_model* mh, int n, const unsigned char* const* pixels, const int* heights, const int* widths, int channels, int S,
+                               unsigned char* const* masks, void* stream) {
+    return guarded([&] {
+        if (!mh || !pixels || !heights || !widths || !masks || n < 1) fail(BRN_ERR_INVALID_ARG, "bad argument");
+        if (!(channels == 3 || channels == 4) || S < 32 || S % 32) fail(BRN_ERR_INVALID_ARG, "infer_images: RGB8 / RGBA8 input and a model size that is a positive multiple of 32 (got %d channels, S = %d)", channels, S);
+        Model& m = mh->m;
+        if (m.decoder_only) fail(BRN_ERR_INVALID_ARG, "this handle holds only the decoder (brn_decoder_create)");
+        for (int i = 0; i < n; ++i)
+            if (!pixels[i] || !masks[i] || heights[i] < 1 || widths[i] < 1) fail(BRN_ERR_INVALID_ARG, "infer_images: image %d is null or empty", i);
+        hipStream_t s = (hipStream_t)stream;
+        auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        std::vector<size_t> o_raw(n), o_tv(n), o_pv(n), o_out(n);
+        size_t total = 0;
+        for (int i = 0; i < n; ++i) { o_raw[i] = total; total += al((size_t)heights[i] * widths[i] * channels); }
+        for (int i = 0; i < n; ++i) { o_tv[i] = total; total += al((size_t)S * widths[i] * channels * sizeof(float)); }
+        const size_t o_x = total; total += al((size_t)n * 3 * S * S * sizeof(float));
+        const size_t o_p = total; total += al((size_t)n * S * S * sizeof(float));
+        const size_t o_m8 = total; total += al((size_t)n * S * S);
+        for (int i = 0; i < n; ++i) { o_pv[i] = total; total += al((size_t)heights[i] * S * sizeof(float)); }
+        for (int i = 0; i < n; ++i) { o_out[i] = total; total += al((size_t)heights[i] * widths[i]); }
+        {
+            std::lock_guard<std::mutex> lk(m.mu);
+            BRN_HIP(hipSetDevice(m.device));
+            if (total > m.io.cap) {
+                if (m.io.base) { BRN_HIP(hipDeviceSynchronize()); (void)hipFree(m.io.base); m.io.base = nullptr; m.io.cap = 0; }
+                void* d = nullptr;
+                hipError_t e = hipMalloc(&d, total);
+                if (e != hipSuccess) { (void)hipGetLastError(); fail(BRN_ERR_OOM, "hipMalloc of %zu bytes for the image staging failed: %s", total, hipGetErrorString(e)); }
+                m.io.base = (char*)d; m.io.cap = total;
+            }
+        }
+        // resampling tables, cached with the handle by (input size, output size, filter); uploaded once
+        auto axis = [&](int in_n, int out_n, int filter) -> const Model::AxisDev& {
+            std::lock_guard<std::mutex> lk(m.mu);
+            for (const Model::AxisDev& a : m.axes) if (a.in_n == in_n && a.out_n == out_n && a.filter == filter) return a;
+            const ResampleAxis ax = make_axis(in_n, out_n, filter);
+            const DevAxis d = upload_axis(m.own, ax);
+            m.axes.push_back({in_n, out_n, filter, d.max_taps, d.left, d.count, d.w});
+            return m.axes.back();
+        };
+        char* base = m.io.base;
+        float* x = reinterpret_cast<float*>(base + o_x);
+        float* prob = reinterpret_cast<float*>(base + o_p);
+        const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};    // infer_image.rs:53-54
+        for (int i = 0; i < n; ++i) {
+            const int h = heights[i], w = widths[i];
+            unsigned char* raw = reinterpret_cast<unsigned char*>(base + o_raw[i]);
+            BRN_HIP(hipMemcpyAsync(raw, pixels[i], (size_t)h * w * channels, hipMemcpyHostToDevice, s));
+            const Model::AxisDev ay = axis(h, S, FILTER_TRIANGLE), ax = axis(w, S, FILTER_TRIANGLE);          // resize_exact(S, S, Triangle)
+            float* tv = reinterpret_cast<float*>(base + o_tv[i]);
+            BRN_HIP(launch_resample_v_u8(raw, h, w, channels, S, ay.left, ay.count, ay.w, ay.max_taps, tv, s));
+            BRN_HIP(launch_resample_h(tv, S, w, channels, S, ax.left, ax.count, ax.w, ax.max_taps, nullptr, x + (size_t)i * 3 * S * S, mean, stdv, s));
+        }
+        run_model(&m, x, n, S, S, BRN_MEM_DEVICE, prob, BRN_MEM_DEVICE, stream, 1);                           // forward(): sigmoid fused (birefnet.rs:466-469)
+        unsigned char* m8 = reinterpret_cast<unsigned char*>(base + o_m8);
+        BRN_HIP(launch_mask_u8(prob, (long)n * S * S, 0, m8, s));                                              // infer_image.rs:84-99
+        for (int i = 0; i < n; ++i) {
+            const int h = heights[i], w = widths[i];
+            const Model::AxisDev ay = axis(S, h, FILTER_LANCZOS3), ax = axis(S, w, FILTER_LANCZOS3);          // :103-108
+            float* pv = reinterpret_cast<float*>(base + o_pv[i]);
+            unsigned char* dout = reinterpret_cast<unsigned char*>(base + o_out[i]);
+            BRN_HIP(launch_resample_v_u8(m8 + (size_t)i * S * S, S, S, 1, h, ay.left, ay.count, ay.w, ay.max_taps, pv, s));
+            BRN_HIP(launch_resample_h(pv, h, S, 1, w, ax.left, ax.count, ax.w, ax.max_taps, dout, nullptr, nullptr, nullptr, s));
+            BRN_HIP(hipMemcpyAsync(masks[i], dout, (size_t)h * w, hipMemcpyDeviceToHost, s));
+        }
+        BRN_HIP(hipStreamSynchronize(s));
+    });
+}
+
 // ---- op-level entry points (weights are always host pointers; x / y / residual follow `loc`) -------------------------------------
 static thread_local int g_op_planes = 0;
 brn_status brn_set_op_compute(int dtype) {

@@ -777,6 +777,7 @@ void model_forward(Model& m, Ctx& c, const float* img, int B, int H, int W, floa
 
 Model::~Model() {
     if (arena.base) (void)hipFree(arena.base);
+    if (io.base) (void)hipFree(io.base);
     for (Side& sd : sides) {
         if (sd.arena.base) (void)hipFree(sd.arena.base);
         if (sd.stream) (void)hipStreamDestroy(sd.stream);

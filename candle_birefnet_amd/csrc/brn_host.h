@@ -205,6 +205,11 @@ struct Model {
     std::vector<Side> sides; hipEvent_t fork_ev = nullptr;
     hipStream_t cu_stream[2] = {nullptr, nullptr}; hipEvent_t cu_join_ev[2] = {nullptr, nullptr};   // BRN_CU_PARTITION: CU-masked streams of the two parts
     std::vector<BranchSet> branch_sets;   // one per sub-batch stream (run_model)
+    // brn_infer_images_u8: device staging of a batch of u8 images + their masks, grown on demand, and the resampling tables by (in, out, filter)
+    struct IoPool { char* base = nullptr; size_t cap = 0; };
+    IoPool io;
+    struct AxisDev { int in_n, out_n, filter, max_taps; int* left; int* count; float* w; };
+    std::vector<AxisDev> axes;
     bool profiling = false;
     bool bf16 = false;        // BRN_BF16: bf16 activations / weights in HBM
     std::vector<LaunchRecord> records;

@@ -40,6 +40,22 @@ def postprocess_mask(logits, out_hw, apply_sigmoid=True, device=0):
     return out
 
 
+def infer_images(model, images, size=1024):
+    """examples/infer_image.rs:44-110 for a batch, end to end on the device (brn_infer_images_u8): `images` = list of uint8 [h, w, 3|4]
+    arrays (all RGB8 or all RGBA8, any sizes) -> list of uint8 masks [h, w].  One forward of the whole batch."""
+    arrs = [np.ascontiguousarray(a, dtype=np.uint8) for a in images]
+    if not arrs or any(a.ndim != 3 or a.shape[2] != arrs[0].shape[2] or a.shape[2] not in (3, 4) for a in arrs):
+        raise ValueError("expected a non-empty list of uint8 [h, w, 3|4] images with the same channel count")
+    n, ch = len(arrs), int(arrs[0].shape[2])
+    outs = [np.empty(a.shape[:2], np.uint8) for a in arrs]
+    pix = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+    msk = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    hs = (C.c_int * n)(*[int(a.shape[0]) for a in arrs])
+    ws = (C.c_int * n)(*[int(a.shape[1]) for a in arrs])
+    _ffi.check(_ffi.lib.brn_infer_images_u8(model._h, n, pix, hs, ws, ch, int(size), msk, None))
+    return outs
+
+
 # ---- minimal PNG codec (8-bit gray / RGB / RGBA, non-interlaced) ----------------------------------------------------
 def read_png(path):
     data = open(path, "rb").read()

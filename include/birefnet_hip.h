@@ -272,6 +272,15 @@ brn_status brn_preprocess_image(const unsigned char* pixels, int h, int w, int c
 brn_status brn_postprocess_mask(const float* logits, int S, brn_mem in_loc, int apply_sigmoid, int out_h, int out_w,
                                 unsigned char* mask_out, int device_ordinal, void* stream);
 
+/* examples/infer_image.rs:44-110 for a BATCH, end to end on the device: n images (host, RGB8 / RGBA8, each its own size) ->
+ * resize_exact(S, S, Triangle) + ImageNet normalisation -> forward() (sigmoid fused) of the whole batch -> `as u8` -> resize back to each
+ * image's own size (Lanczos3) -> n masks on the host (masks[i]: heights[i] x widths[i] bytes).  One call: the uploads, 4 small kernels
+ * per image, ONE forward of batch n, the downloads; no allocation after the first call of a shape (the staging buffers and the
+ * resampling tables live with the model handle and are reused), one stream synchronisation at the end.  Results are bit-identical to
+ * brn_preprocess_image -> brn_forward -> brn_postprocess_mask image by image when the forward runs the same batch. */
+brn_status brn_infer_images_u8(brn_model* m, int n, const unsigned char* const* pixels, const int* heights, const int* widths,
+                               int channels, int S, unsigned char* const* masks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -129,6 +129,8 @@ extern "C" {
                               device_ordinal: c_int, stream: *mut c_void) -> c_int;
     pub fn brn_preprocess_image(pixels: *const c_uchar, h: c_int, w: c_int, channels: c_int, s: c_int, x_nchw_out: *mut c_float,
                                 out_loc: c_int, device_ordinal: c_int, stream: *mut c_void) -> c_int;
+    pub fn brn_infer_images_u8(m: *mut BrnModel, n: c_int, pixels: *const *const c_uchar, heights: *const c_int, widths: *const c_int, channels: c_int,
+                               s: c_int, masks: *const *mut c_uchar, stream: *mut c_void) -> c_int;
     pub fn brn_postprocess_mask(logits: *const c_float, s: c_int, in_loc: c_int, apply_sigmoid: c_int, out_h: c_int, out_w: c_int,
                                 mask_out: *mut c_uchar, device_ordinal: c_int, stream: *mut c_void) -> c_int;
 }

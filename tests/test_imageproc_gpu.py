@@ -80,3 +80,32 @@ def test_imageproc_size_fuzz(gpu):
     pr = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "imageproc_fuzz.py"), "40", "7"], capture_output=True, text=True, timeout=900)
     assert pr.returncode == 0, pr.stderr[-2000:]
     assert "40 cases, 0 problems" in pr.stdout, pr.stdout[-3000:]
+
+
+def test_infer_images_batch_equals_image_by_image(gpu):
+    """brn_infer_images_u8 (examples/infer_image.rs:44-110 for a batch: uploads, resize + normalise, ONE forward of the batch, u8, resize
+    back, downloads) against the three single-image entry points chained by hand with the same batched forward: bit-identical masks;
+    mixed image sizes, RGB and RGBA, a second call on the cached staging / tables, a larger batch that regrows the staging."""
+    import torch
+    import candle_birefnet_amd as cb
+    from candle_birefnet_amd.imageproc import infer_images, postprocess_mask, preprocess_image
+    cfg = cb.BiRefNetConfig()
+    cfg.swin.depths = [2, 2, 2, 2]
+    w = cb.synth_weights(cb.birefnet_weight_spec(cfg), seed=42)
+    S = 128
+    for compute in ("f32_split3", "bf16"):
+        m = cb.BiRefNet.new(cfg, cb.VarBuilder.from_tensors(w), compute=compute)
+        rng = np.random.default_rng(5)
+        for ch, sizes in ((3, [(150, 97), (64, 64), (33, 201)]), (4, [(90, 90), (128, 128), (77, 140), (200, 30), (55, 66)])):
+            imgs = [rng.integers(0, 256, (h, wd, ch), dtype=np.uint8) for h, wd in sizes]
+            masks = infer_images(m, imgs, S)
+            masks2 = infer_images(m, imgs, S)
+            x = torch.cat([preprocess_image(im, S) for im in imgs], 0)
+            p = m.forward(x)
+            for im, mk, mk2, pi in zip(imgs, masks, masks2, p):
+                assert mk.shape == im.shape[:2] and mk.dtype == np.uint8
+                np.testing.assert_array_equal(mk, mk2)
+                np.testing.assert_array_equal(mk, postprocess_mask(pi[None], im.shape[:2], apply_sigmoid=False))
+        with pytest.raises(cb.BrnError):
+            infer_images(m, [np.zeros((10, 10, 3), np.uint8)], 100)       # S not a multiple of 32
+        m.close()
