@@ -580,8 +580,8 @@ void aspp_forward(Ctx& c, const ASPPW& a, const Map& t, const Map& u, int deform
             for (int i = 0; i < 4; ++i) {
                 Branch br(c, i < 3 ? i : -1);
                 const DeformW& d = a.d[i];
-                const int kk = d.k * d.k, ldom = roundup(3 * kk, 4);
-                Map om; om.B = B; om.H = H; om.W = W; om.C = 3 * kk; om.ld = ldom; om.coff = 0;
+                const int kk = d.k * d.k, ldom = d.offmod.N;         // 3 k^2 rounded up to 8 (zero filters: build_aspp_weights)
+                Map om; om.B = B; om.H = H; om.W = W; om.C = ldom; om.ld = ldom; om.coff = 0;
                 om.p = c.arena->alloc((size_t)M * ldom);             // offsets / modulator stay fp32 in every mode
                 run_conv(c, d.offmod, t, om, nullptr, 0, 0, 1);      // offset_conv | modulator_conv (aspp.rs:171,173)
                 const bool fused_sig = deform_fused_sigmoid(c, d.regular);   // bf16 gather kernel: 2*sigmoid applied where the modulator is read

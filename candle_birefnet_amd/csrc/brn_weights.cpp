@@ -3,6 +3,7 @@
 // to the tile), fold eval-mode BatchNorm into per-channel scale/shift, precompute the transposed relative-position
 // bias per block (the analogue of WindowAttention::cached_bias, swin.rs:147-152), upload once.
 #include "brn_host.h"
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <cstdio>
@@ -365,12 +366,16 @@ void build_aspp_weights(const WeightTable& wt, const std::string& ap, int deform
         if (deform_mode == BRN_DEFORM_DEFORMABLE) {
             d.regular.mode = GEMM_DEFORM_NHWC;
             attach_deform_frags(own, d.regular, wt.get(cp + "regular_conv.weight", {PL, IC, k, k})->data);
-            std::vector<float> w3((size_t)3 * kk * IC * kk), b3((size_t)3 * kk);
+            // offset_conv and modulator_conv stacked on N = 3 k^2, padded with zero filters to a multiple of 8 (3 / 27 / 147 -> 8 / 32 / 152): the
+            // fp32 offset map then leaves the bf16 GEMM through its vector-store epilogue instead of the per-element one
+            static const bool pad8 = !(getenv("BRN_OFFMOD_PAD8") && atoi(getenv("BRN_OFFMOD_PAD8")) == 0);   // (A/B switch: 0 = pad to 4 as before)
+            const int n3p = roundup(3 * kk, pad8 ? 8 : 4);
+            std::vector<float> w3((size_t)n3p * IC * kk, 0.f), b3((size_t)n3p, 0.f);
             memcpy(w3.data(), ow, (size_t)2 * kk * IC * kk * sizeof(float));
             memcpy(w3.data() + (size_t)2 * kk * IC * kk, mw, (size_t)kk * IC * kk * sizeof(float));
             memcpy(b3.data(), ob, (size_t)2 * kk * sizeof(float));
             memcpy(b3.data() + 2 * kk, mb, (size_t)kk * sizeof(float));
-            d.offmod = make_conv_nhwc(own, w3.data(), b3.data(), 3 * kk, IC, ICP, k, k, 1, k / 2, 1);
+            d.offmod = make_conv_nhwc(own, w3.data(), b3.data(), n3p, IC, ICP, k, k, 1, k / 2, 1);
         }
     }
     if (deform_mode == BRN_DEFORM_REFERENCE_CPU) {
