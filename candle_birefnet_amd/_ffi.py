@@ -83,6 +83,7 @@ _sig("brn_forward", C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, 
 _sig("brn_model_backbone_forward", C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp), C.c_int, _vp)
 _sig("brn_model_squeeze_forward", C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp)
 _sig("brn_model_decoder_forward", C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp)
+_sig("brn_model_set_streams", C.c_int, _vp, C.c_int, C.c_int)
 _sig("brn_model_set_profiling", C.c_int, _vp, C.c_int)
 _sig("brn_model_last_timings", C.c_int, _vp, C.POINTER(C.c_float * 5))
 _sig("brn_model_last_kernel_stats", C.c_int, _vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_double),
@@ -121,7 +122,7 @@ DECLARED = [
     "brn_abi_version", "brn_last_error", "brn_build_info", "brn_device_count", "brn_config_default_swin_l",
     "brn_config_lateral_channels", "brn_config_x4_channels", "brn_model_create", "brn_model_create_from_safetensors", "brn_decoder_create", "brn_model_destroy", "brn_forward_logits",
     "brn_forward", "brn_model_backbone_forward", "brn_model_squeeze_forward", "brn_model_decoder_forward",
-    "brn_model_set_profiling", "brn_model_last_timings", "brn_model_last_kernel_stats", "brn_kernel_family_name",
+    "brn_model_set_streams", "brn_model_set_profiling", "brn_model_last_timings", "brn_model_last_kernel_stats", "brn_kernel_family_name",
     "brn_swin_create", "brn_swin_destroy", "brn_swin_forward", "brn_linear_forward", "brn_linear_residual_layer_norm_forward", "brn_layer_norm_forward",
     "brn_conv2d_forward", "brn_upsample_bilinear2d", "brn_window_attention_forward", "brn_patch_merging_forward",
     "brn_deform_conv2d_forward", "brn_aspp_deformable_forward", "brn_decblk_forward", "brn_set_op_compute", "brn_preprocess_image", "brn_postprocess_mask", "brn_infer_images_u8",

@@ -136,6 +136,10 @@ class BiRefNet:
                                                       T.stream_of(args[0][2])))
         return out
 
+    def set_streams(self, sub_batch_streams: int = 0, branch_stream_mask: int = -1):
+        """how a forward is spread over HIP streams (brn_model_set_streams); 0 / -1 = the library defaults"""
+        _ffi.check(_ffi.lib.brn_model_set_streams(self._h, int(sub_batch_streams), int(branch_stream_mask)))
+
     # -- timers mirroring bench_inference.rs:37-92 --
     def set_profiling(self, on: bool):
         _ffi.check(_ffi.lib.brn_model_set_profiling(self._h, int(bool(on))))

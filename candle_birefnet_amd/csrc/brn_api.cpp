@@ -167,9 +167,10 @@ static void validate_config(const brn_config& c) {
 static void run_model_locked(Model* m, const float* x, int B, int H, int W, brn_mem in_loc, float* out, brn_mem out_loc, void* stream, int apply_sigmoid);
 
 // sub-batches a device-resident batch of B images runs as (BRN_SPLIT_STREAMS, default 2; at least two images per part)
-static int sub_batch_parts(int B) {
+static int sub_batch_parts(int B, int override_parts = 0) {
     static const int parts_env = getenv("BRN_SPLIT_STREAMS") ? atoi(getenv("BRN_SPLIT_STREAMS")) : 2;
-    int parts = parts_env < 1 ? 1 : (parts_env > 8 ? 8 : parts_env);
+    const int want = override_parts > 0 ? override_parts : parts_env;     // brn_model_set_streams beats the environment
+    int parts = want < 1 ? 1 : (want > 8 ? 8 : want);
     if (parts > B / 2) parts = B / 2;
     return parts < 1 ? 1 : parts;
 }
@@ -220,7 +221,7 @@ static void run_model_locked(Model* m, const float* x, int B, int H, int W, brn_
     // a device-resident batch runs as `parts` sub-batches, each on its own stream with its own workspace (below): what has to fit a
     // workspace is then the LARGEST PART, and that is the shape the dry run plans (its GEMM plans — tiles, split-K scratch — are those of
     // the part, not of the whole batch); every workspace, the main one included, is sized to that peak
-    int parts = sub_batch_parts(B);
+    int parts = sub_batch_parts(B, m->opt_parts);
     bool split = parts > 1 && !m->profiling && in_loc == BRN_MEM_DEVICE && out_loc == BRN_MEM_DEVICE;
     plan_model(*m, split ? (B + parts - 1) / parts : B, H, W);
     if (split && !ensure_side_arenas(*m, parts)) {
@@ -255,7 +256,8 @@ static void run_model_locked(Model* m, const float* x, int B, int H, int W, brn_
     // Default: on when the batch runs as ONE part (measured: +1.4 % at batch 1, 1024^2; with two sub-batch streams the extra
     // concurrency costs 2.5 % at batch 8); a positive value is the mask of auxiliary streams to use, for every batch
     // (31 = all: 7 the ASPP branches, 8 the image-patch convolutions, 16 the lateral convolutions).
-    static const int branches_env = getenv("BRN_BRANCH_STREAMS") ? atoi(getenv("BRN_BRANCH_STREAMS")) : -1;
+    static const int branches_env0 = getenv("BRN_BRANCH_STREAMS") ? atoi(getenv("BRN_BRANCH_STREAMS")) : -1;
+    const int branches_env = m->opt_branches > -2 ? m->opt_branches : branches_env0;    // brn_model_set_streams beats the environment
     bool branches_on = branches_env != 0;
     auto branch_set = [&](int k) -> BranchSet* {
         if (!branches_on || m->profiling) return nullptr;
@@ -409,7 +411,7 @@ brn_status brn_model_create(const brn_config* cfg, const brn_named_tensor* weigh
         m.has_decoder = true;
         // (the batch the caller announces will run as sub_batch_parts(max_batch) parts when it is device-resident: plan the part;
         // a host-resident or profiled call of that batch re-plans for the whole batch when it comes)
-        if (max_batch > 0 && max_h > 0 && max_w > 0) { const int pp = sub_batch_parts(max_batch); plan_model(m, (max_batch + pp - 1) / pp, max_h, max_w); }
+        if (max_batch > 0 && max_h > 0 && max_w > 0) { const int pp = sub_batch_parts(max_batch, m.opt_parts); plan_model(m, (max_batch + pp - 1) / pp, max_h, max_w); }
         *out = h.release();
     });
 }
@@ -465,6 +467,16 @@ brn_status brn_forward(brn_model* m, const float* x, int B, int H, int W, brn_me
     return guarded([&] { run_model(m ? &m->m : nullptr, x, B, H, W, in_loc, out, out_loc, stream, 1); });
 }
 
+brn_status brn_model_set_streams(brn_model* m, int sub_batch_streams, int branch_stream_mask) {
+    return guarded([&] {
+        if (!m) fail(BRN_ERR_INVALID_ARG, "null model");
+        if (sub_batch_streams < 0 || sub_batch_streams > 8 || branch_stream_mask < -1 || branch_stream_mask > 31)
+            fail(BRN_ERR_INVALID_ARG, "sub_batch_streams in 0 .. 8 (0 = default), branch_stream_mask in -1 .. 31 (-1 = automatic)");
+        std::lock_guard<std::mutex> lk(m->m.mu);
+        m->m.opt_parts = sub_batch_streams;
+        m->m.opt_branches = branch_stream_mask;
+    });
+}
 brn_status brn_model_set_profiling(brn_model* m, int enable) {
     return guarded([&] {
         if (!m) fail(BRN_ERR_INVALID_ARG, "null model");

@@ -211,6 +211,8 @@ struct Model {
     struct AxisDev { int in_n, out_n, filter, max_taps; int* left; int* count; float* w; };
     std::vector<AxisDev> axes;
     bool profiling = false;
+    int opt_parts = 0;        // brn_model_set_streams: sub-batch streams of a device-resident batch (0 = BRN_SPLIT_STREAMS / default 2)
+    int opt_branches = -2;    // ... and the mask of auxiliary branch streams (-2 = BRN_BRANCH_STREAMS / default; -1 = automatic; 0 = none)
     bool bf16 = false;        // BRN_BF16: bf16 activations / weights in HBM
     std::vector<LaunchRecord> records;
     std::vector<hipEvent_t> event_pool; size_t event_next = 0;

@@ -159,6 +159,13 @@ brn_status brn_model_decoder_forward(brn_model* m, const float* x_nchw, const fl
 brn_status brn_decoder_create(const brn_config* cfg, const brn_named_tensor* weights, size_t n_weights, const char* prefix,
                               int device_ordinal, brn_dtype compute_dtype, brn_model** out);
 
+/* How a forward is spread over HIP streams (it never changes what is computed per image; results for a given setting are repeatable bit
+ * for bit).  sub_batch_streams: a device-resident batch of B >= 4 images runs as that many sub-batches (>= 2 images each) on as many
+ * streams, forked from and joined to the caller's stream, each with its own workspace (0 = library default: 2, or BRN_SPLIT_STREAMS;
+ * 1 = everything on the caller's stream).  branch_stream_mask: independent branches of one forward on auxiliary streams — bits 0-2 the
+ * ASPP branches, 3 the image-patch convolutions, 4 the lateral convolutions; -1 = automatic (on when the batch runs as one part), 0 = off. */
+brn_status brn_model_set_streams(brn_model* m, int sub_batch_streams, int branch_stream_mask);
+
 /* Per-stage wall time of the last forward on this handle, measured with HIP events on the call's stream:
  * [0]=backbone full, [1]=backbone half+fusion, [2]=squeeze, [3]=decoder, [4]=total (ms).  Mirrors the timers of
  * bench_inference.rs:37-92.  Enabled by brn_model_set_profiling(m, 1) (adds event records + one sync). */

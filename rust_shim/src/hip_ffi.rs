@@ -86,6 +86,7 @@ extern "C" {
     pub fn brn_model_decoder_forward(m: *mut BrnModel, x_nchw: *const c_float, x1: *const c_float, x2: *const c_float,
                                      x3: *const c_float, x4: *const c_float, b: c_int, h: c_int, w: c_int, in_loc: c_int,
                                      logits_out: *mut c_float, out_loc: c_int, stream: *mut c_void) -> c_int;
+    pub fn brn_model_set_streams(m: *mut BrnModel, sub_batch_streams: c_int, branch_stream_mask: c_int) -> c_int;
     pub fn brn_model_set_profiling(m: *mut BrnModel, enable: c_int) -> c_int;
     pub fn brn_model_last_timings(m: *mut BrnModel, ms: *mut c_float) -> c_int;
     pub fn brn_model_last_kernel_stats(m: *mut BrnModel, n: c_int, launches: *mut c_int, ms: *mut c_float, flop: *mut c_double,

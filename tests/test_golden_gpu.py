@@ -151,3 +151,29 @@ def test_branch_streams_do_not_change_results(gpu, tmp_path, mode):
     for k in res["0"].files:
         np.testing.assert_array_equal(res["0"][k], res[""][k])
         np.testing.assert_array_equal(res["0"][k], res["31"][k])
+
+
+def test_set_streams_through_the_abi(gpu):
+    """brn_model_set_streams: the stream layout of a forward chosen per handle through the ABI (what BRN_SPLIT_STREAMS / BRN_BRANCH_STREAMS
+    choose per process).  Branch streams never change a bit; one sub-batch stream gives the bits of the same call on a fresh handle with
+    the batch as one part; two sub-batches compute the same images with the plans of a smaller batch: equal to the mode's rounding and
+    bit-equal to running the two halves as two calls."""
+    import torch
+    import candle_birefnet_amd as cb
+    cfg, w, x = G.model_case(sorted(G.MODEL_CASES)[0])
+    xb = torch.from_numpy(np.concatenate([x, x[:, :, ::-1].copy(), x[:, :, :, ::-1].copy(), -x])[:4].copy()).cuda()
+    for compute in ("f32_split3", "bf16"):
+        m = cb.BiRefNet.new(cfg, cb.VarBuilder.from_tensors(w), compute=compute)
+        m.set_streams(1, 0)
+        y_one = m.forward_logits(xb).cpu().numpy()
+        m.set_streams(1, 31)
+        np.testing.assert_array_equal(m.forward_logits(xb).cpu().numpy(), y_one)
+        m.set_streams(2, -1)
+        y_two = m.forward_logits(xb).cpu().numpy()
+        m.set_streams(1, -1)
+        halves = np.concatenate([m.forward_logits(xb[:2]).cpu().numpy(), m.forward_logits(xb[2:]).cpu().numpy()])
+        np.testing.assert_array_equal(y_two, halves)
+        assert np.abs(y_two - y_one).max() < (3e-2 if compute == "bf16" else 2e-5)
+        with pytest.raises(cb.BrnError):
+            m.set_streams(9, 0)
+        m.close()
