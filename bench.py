@@ -110,6 +110,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off", "on"])
     ap.add_argument("--other-configs", default="auto", choices=["auto", "off", "on"],
                     help="time the other BASELINE configurations in the same run (auto: with the default c2 line)")
+    ap.add_argument("--mask-error", default="on", choices=["on", "off"],
+                    help="one extra forward() of image 0 after the timed region for the mask-space error (off: rocprofv3 passes count only the timed forwards)")
     ap.add_argument("--cpu-baseline-size", type=int, default=0, help="image side for the CPU sample (0 = the workload's side, capped at 1024)")
     ap.add_argument("--cpu-torch-worker", type=int, default=0, help=argparse.SUPPRESS)
     return ap.parse_args(argv)
@@ -457,7 +459,7 @@ def main(argv=None):
             m2.close()
     gold_headline = golden_error(y, S, args.deform_mode) if (rank == 0 and not custom) else None
     # mask space: forward() = sigmoid(logits) (birefnet.rs:466-469) of image 0 against sigmoid(golden logits)
-    gold_mask_headline = golden_error(model.forward(x[:1]), S, args.deform_mode, mask=True) if (rank == 0 and not custom) else None
+    gold_mask_headline = golden_error(model.forward(x[:1]), S, args.deform_mode, mask=True) if (rank == 0 and not custom and args.mask_error == "on") else None
     model.close()
     del model, x, y
 
