@@ -45,6 +45,8 @@ MODES = {
     "f32_split3": (6, "f32 storage+accumulate; GEMM operands split error-free into 3 bf16 terms, 6 bf16 MFMAs/product (fp32-equivalent)", 4),
     "f32_split2": (3, "f32 storage+accumulate; GEMM operands split into 2 bf16 terms (16-bit mantissa), 3 bf16 MFMAs/product", 4),
     "bf16": (1, "bf16 (activations and weights stored bf16 in HBM, bf16 MFMA, f32 accumulate / LayerNorm / softmax statistics)", 2),
+    "bf16_dec_split2": (1, "mixed: Swin backbone as bf16 (79 % of the FLOPs), fusion / squeeze / decoder as f32_split2 on f32 maps (3 bf16 MFMAs / product); "
+                           "roofline priced against the bf16 peak", 2),
 }
 GEMM_FAMILIES = ("gemm_dense", "gemm_conv_nhwc", "gemm_gather_nchw", "gemm_deform_nhwc")
 HBM_PEAK_TBS = 8.0                     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 measured with a float4 copy)
@@ -467,11 +469,17 @@ def main(argv=None):
     other_cfgs = None
     if others_on:
         other_cfgs = {}
-        plan = ([("c3", "reference_cpu"), ("c3", "deformable"), ("c5", "reference_cpu"), ("c5", "deformable")] if world == 1 else
-                [("c4", "reference_cpu"), ("c4", "deformable")])
-        for cname, dm in plan:
+        # (the last c3 entry: the same workload in the mixed mode — bf16 backbone, f32_split2 fusion / squeeze / decoder — the arithmetic
+        # that brings the mask-space error of the reference_cpu configuration under 1e-3; reported beside c3, it does not replace it)
+        plan = ([("c3", "reference_cpu", None), ("c3", "deformable", None), ("c5", "reference_cpu", None), ("c5", "deformable", None),
+                 ("c3", "reference_cpu", "bf16_dec_split2")] if world == 1 else
+                [("c4", "reference_cpu", None), ("c4", "deformable", None)])
+        for cname, dm, cmode_over in plan:
             oB, oS, omode, olabel = CONFIGS[cname]
             key = cname + ("_deformable" if dm == "deformable" else "")
+            if cmode_over:
+                omode, key = cmode_over, f"{key}_{cmode_over}"
+                olabel = olabel.replace(" bf16 ", f" {cmode_over} ")
             if rank == 0:
                 log(f"other config {key}: {omode}, B={oB}/GPU, {oS}x{oS}, {dm}; warmup {OTHER_WARMUP} + {OTHER_STEPS} timed steps")
             t_o, pr_o, _, m_o, x_o, y_o = timed_workload(oB, oS, omode, dm, OTHER_STEPS, OTHER_WARMUP)

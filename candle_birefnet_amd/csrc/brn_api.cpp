@@ -393,7 +393,7 @@ brn_status brn_model_create(const brn_config* cfg, const brn_named_tensor* weigh
 #else
         else if (dt == BRN_BF16_OPERANDS) fail(BRN_ERR_INVALID_ARG, "compute dtype BRN_BF16_OPERANDS is superseded by BRN_BF16 and only built into libbirefnet_hip_diag.so");
 #endif
-        else if (dt == BRN_BF16) planes = BUILD_BF16;
+        else if (dt == BRN_BF16 || dt == BRN_BF16_DEC_SPLIT2) planes = BUILD_BF16;
         else fail(BRN_ERR_INVALID_ARG, "unsupported compute dtype %d", (int)dt);
         struct PlanesGuard { PlanesGuard(int p) { set_build_planes(p); } ~PlanesGuard() { set_build_planes(0); } } guard(planes);
         *out = nullptr;
@@ -401,9 +401,10 @@ brn_status brn_model_create(const brn_config* cfg, const brn_named_tensor* weigh
         validate_config(*cfg);
         std::unique_ptr<brn_model> h(new brn_model());
         Model& m = h->m;
-        m.cfg = *cfg; m.device = device; m.bf16 = dt == BRN_BF16;
+        m.cfg = *cfg; m.device = device; m.bf16 = planes == BUILD_BF16; m.dec_bf16 = dt == BRN_BF16;
         WeightTable wt(weights, n);
         build_swin_weights(wt, "bb.", *cfg, m.own, m.swin);                               // birefnet.rs:393
+        if (dt == BRN_BF16_DEC_SPLIT2) set_build_planes(2);                               // squeeze + decoder weights as two bf16 planes (mode f32_split2)
         int lat[4];
         brn_config_lateral_channels(cfg, lat);
         build_decblk_weights(wt, "squeeze_module.0.", brn_config_x4_channels(cfg), lat[3], cfg->deform_mode, m.own, m.squeeze);   // birefnet.rs:397-399
@@ -424,6 +425,7 @@ brn_status brn_decoder_create(const brn_config* cfg, const brn_named_tensor* wei
         else if (dt == BRN_F32_SPLIT3) planes = 3;
         else if (dt == BRN_F32_SPLIT2) planes = 2;
         else if (dt == BRN_BF16) planes = BUILD_BF16;
+        else if (dt == BRN_BF16_DEC_SPLIT2) planes = 2;                                    // (a decoder on its own in the mixed mode = mode f32_split2)
         else fail(BRN_ERR_INVALID_ARG, "unsupported compute dtype %d", (int)dt);
         struct PlanesGuard { PlanesGuard(int p) { set_build_planes(p); } ~PlanesGuard() { set_build_planes(0); } } guard(planes);
         *out = nullptr;
@@ -431,7 +433,7 @@ brn_status brn_decoder_create(const brn_config* cfg, const brn_named_tensor* wei
         validate_config(*cfg);
         std::unique_ptr<brn_model> h(new brn_model());
         Model& m = h->m;
-        m.cfg = *cfg; m.device = device; m.bf16 = dt == BRN_BF16;
+        m.cfg = *cfg; m.device = device; m.bf16 = dt == BRN_BF16; m.dec_bf16 = m.bf16;
         WeightTable wt(weights, n);
         build_decoder_weights(wt, prefix ? prefix : "", *cfg, m.own, m.dec);               // birefnet.rs:170-273
         m.has_decoder = true; m.decoder_only = true;
@@ -562,7 +564,7 @@ brn_status brn_model_squeeze_forward(brn_model* m, const float* x4, int B, int h
             if (!c.dry) BRN_HIP(launch_nchw_to_nhwc(dx, B, cin, h, w, X.p, X.ld, 0, c.stream, c.bf16));
             decblk_forward(c, m->m.squeeze, X, Y, m->m.cfg.deform_mode);
             if (!c.dry) BRN_HIP(launch_nhwc_to_nchw(Y.p, B, cout, h, w, Y.ld, 0, dy, c.stream, c.bf16));
-        }, m->m.bf16);
+        }, m->m.dec_bf16);
         so.finish();
     });
 }
@@ -593,7 +595,7 @@ brn_status brn_model_decoder_forward(brn_model* m, const float* x, const float* 
                 BRN_HIP(launch_nchw_to_nhwc(dsrc[3], B, 3072, hh[3], ww[3], D4.p, D4.ld, 0, c.stream, c.bf16));
             }
             decoder_forward(c, m->m, dx, B, H, W, X1, X2, X3, D4, dy, 0);
-        }, m->m.bf16);
+        }, m->m.dec_bf16);
         so.finish();
     });
 }

@@ -396,7 +396,7 @@ void swin_attention(Ctx& c, const SwinBlockW& blk, const float* xn, int B, int H
     swin_attention_multi(c, blk, xn, B, 1, &H, &W, C, shift, y, residual, 0, window);
 }
 
-void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int B) {
+void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int B, bool outs_f32) {
     if (nin < 1 || nin > 2) fail(BRN_ERR_INVALID_ARG, "swin_forward_multi: 1 or 2 inputs");
     int hs[2][4], wsz[2][4];
     for (int k = 0; k < nin; ++k) swin_stage_dims(ins[k].H, ins[k].W, w.patch, hs[k], wsz[k]);
@@ -494,7 +494,7 @@ void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int 
         for (int k = 0; k < nin; ++k) {
             const Map& o = ins[k].outs[i];
             if (o.B != B || o.H != hh[k] || o.W != ww[k] || o.C != C) fail(BRN_ERR_INVALID_ARG, "swin output window %d has the wrong shape", i);
-            run_layernorm(c, st.out_norm, x + off * C, rows(k, i), C, o.p, o.ld, o.coff, 0, yb);
+            run_layernorm(c, st.out_norm, x + off * C, rows(k, i), C, o.p, o.ld, o.coff, 0, outs_f32 ? 0 : yb);
             if (st.has_down) {
                 // PatchMerging (swin.rs:491-527): gather 2x2 + LN(4C) fused, then the bias-free reduction (below, once)
                 const int M2 = rows(k, i + 1);
@@ -717,6 +717,10 @@ void model_forward(Model& m, Ctx& c, const float* img, int B, int H, int W, floa
         fail(BRN_ERR_INVALID_ARG, "input %dx%d: H and W must be positive multiples of 32 (image2patches, birefnet.rs:288-300)", H, W);
     const bool prof = c.profile && !c.dry && m.stage_ev_ok;
     auto stamp = [&](int i) { if (prof) BRN_HIP(hipEventRecord(m.stage_ev[i], c.stream)); };
+    // Ctx::bf16 says what the maps being allocated / the kernels being launched hold: the backbone's setting (m.bf16) inside
+    // swin_forward_multi, the decoder side's (m.dec_bf16) everywhere else — the two differ only in the mixed mode BRN_BF16_DEC_SPLIT2
+    struct Bf16Scope { Ctx& c; bool old; Bf16Scope(Ctx& c_, bool v) : c(c_), old(c_.bf16) { c.bf16 = v; } ~Bf16Scope() { c.bf16 = old; } };
+    Bf16Scope dec_scope(c, m.dec_bf16);
     const size_t mk = c.arena->mark();
     const int h1 = H / 4, w1 = W / 4, h2 = H / 8, w2 = W / 8, h3 = H / 16, w3 = W / 16, h4 = H / 32, w4 = W / 32;
     // multi-scale concat targets (birefnet.rs:440-443) and the context concat (birefnet.rs:453): [x1|x2|x3|x4] at 1/32
@@ -747,7 +751,10 @@ void model_forward(Model& m, Ctx& c, const float* img, int B, int H, int W, floa
         for (int i = 0; i < 4; ++i) hm[i] = new_map(c, B, hs[i], ws[i], 192 << i);
         Map outs[4] = {X1.window(0, 192), X2.window(0, 384), X3.window(0, 768), X4.window(2688, 1536)};
         SwinIn ins[2] = {{img, H, W, outs}, {half, Hh, Wh, hm}};
-        swin_forward_multi(c, m.swin, ins, 2, B);
+        {
+            Bf16Scope bb_scope(c, m.bf16);
+            swin_forward_multi(c, m.swin, ins, 2, B, m.bf16 && !m.dec_bf16);
+        }
         stamp(1);
         run_resize(c, hm[0], X1.window(192, 192));                                    // birefnet.rs:435-443
         run_resize(c, hm[1], X2.window(384, 384));

@@ -213,7 +213,8 @@ struct Model {
     bool profiling = false;
     int opt_parts = 0;        // brn_model_set_streams: sub-batch streams of a device-resident batch (0 = BRN_SPLIT_STREAMS / default 2)
     int opt_branches = -2;    // ... and the mask of auxiliary branch streams (-2 = BRN_BRANCH_STREAMS / default; -1 = automatic; 0 = none)
-    bool bf16 = false;        // BRN_BF16: bf16 activations / weights in HBM
+    bool bf16 = false;        // BRN_BF16 / BRN_BF16_DEC_SPLIT2: the backbone's activations / weights are bf16 in HBM
+    bool dec_bf16 = false;    // the fusion / squeeze / decoder part too (BRN_BF16); false in BRN_BF16_DEC_SPLIT2: fp32 maps, split-bf16 GEMMs
     std::vector<LaunchRecord> records;
     std::vector<hipEvent_t> event_pool; size_t event_next = 0;
     hipEvent_t stage_ev[6]; bool stage_ev_ok = false;
@@ -265,8 +266,9 @@ bool linear_residual_ln(Ctx& c, const GemmW& w, const float* A, int M, int lda, 
 void swin_forward(Ctx& c, const SwinW& w, const float* img_nchw, int B, int H, int W, const Map outs[4]);
 void swin_stage_dims(int H, int W, int patch, int hs[4], int ws[4]);
 struct SwinIn { const float* img; int H, W; const Map* outs; };   // one backbone input and its 4 destination windows
-// 1 or 2 inputs through the same weights in one pass over concatenated token rows
-void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int B);
+// 1 or 2 inputs through the same weights in one pass over concatenated token rows; outs_f32: in compute mode BRN_BF16 the stage outputs
+// (norm_i of the fp32 residual stream) are written as fp32 maps (the mixed mode, whose decoder runs on fp32 maps)
+void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int B, bool outs_f32 = false);
 // the attention half of one block (swin.rs:356-403), x is the norm1 output, y = proj(attn) (no residual) or += residual
 void swin_attention(Ctx& c, const SwinBlockW& blk, const float* xn, int B, int H, int W, int C, int shift,
                     float* y, const float* residual, int window = 12);

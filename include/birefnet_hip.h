@@ -53,8 +53,11 @@ typedef enum { BRN_MEM_HOST = 0, BRN_MEM_DEVICE = 1 } brn_mem;
  *                      product library answers BRN_ERR_INVALID_ARG (only libbirefnet_hip_diag.so, `make diag`, still builds it)
  *   BRN_BF16           the bf16 throughput mode of BASELINE configs[2..4]: activations AND weights live in HBM as bf16,
  *                      bf16 MFMA with fp32 accumulation, fp32 statistics inside LayerNorm / softmax / GAP; x and the logits
- *                      stay fp32 at this boundary.  Parity is informational (error vs the fp32 oracle is reported). */
-typedef enum { BRN_F32 = 0, BRN_F32_SPLIT3 = 1, BRN_F32_SPLIT2 = 2, BRN_BF16_OPERANDS = 3, BRN_BF16 = 4 } brn_dtype;
+ *                      stay fp32 at this boundary.  Parity is informational (error vs the fp32 oracle is reported).
+ *   BRN_BF16_DEC_SPLIT2  mixed: the Swin backbone (79 % of the FLOPs) as BRN_BF16, everything after it — multi-scale / context fusion,
+ *                      squeeze module, decoder — as BRN_F32_SPLIT2 on fp32 maps.  The decoder's ~20 chained bf16 roundings are most of mode
+ *                      BRN_BF16's error; this mode pays for removing them where they are cheapest. */
+typedef enum { BRN_F32 = 0, BRN_F32_SPLIT3 = 1, BRN_F32_SPLIT2 = 2, BRN_BF16_OPERANDS = 3, BRN_BF16 = 4, BRN_BF16_DEC_SPLIT2 = 5 } brn_dtype;
 
 /* D1 of SURVEY.md §8: what DeformConvASPP::forward computes.
  * REFERENCE_CPU = aspp.rs:183-185 (offset/modulator discarded, regular_conv(x)) — the graded parity target.

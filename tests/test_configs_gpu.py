@@ -271,3 +271,41 @@ def test_sub_batch_workspace_is_planned_for_the_part_and_falls_back(gpu, tmp_pat
     # the second workspace is allocated at the first split forward and is no larger than a part needs: the device memory taken by the
     # first forward (side workspace) is at most what the handle reserved at creation for the main one (+ allocator slack)
     print("device memory taken by the first forward: split %d MB, one stream %d MB" % (outs["split"]["grew"] >> 20, outs["one"]["grew"] >> 20))
+
+
+def test_mixed_mode_bf16_backbone_split2_decoder(gpu):
+    """BRN_BF16_DEC_SPLIT2 (compute "bf16_dec_split2"): the backbone as mode bf16, fusion / squeeze / decoder as mode f32_split2 on fp32
+    maps — the decoder's chained bf16 roundings are most of mode bf16's error.  Small full-depth goldens in both
+    deform modes (finite, repeatable, between the two pure modes), the piece-wise entries (backbone = the bf16 one bit for bit, decoder =
+    the f32_split2 one bit for bit), and c3 (B = 8, 1024^2, reference_cpu): the mask-space error of image 0 under the north star's 1e-3."""
+    import torch
+    import candle_birefnet_amd as cb
+    k = np.load(os.path.join(GOLD, "models_small.npz"))
+    for tag in sorted(G.MODEL_CASES):
+        cfg, w, x = G.model_case(tag)
+        vb = cb.VarBuilder.from_tensors(w)
+        ms = {c: cb.BiRefNet.new(cfg, vb, compute=c) for c in ("bf16_dec_split2", "bf16", "f32_split2")}
+        y = {c: np.asarray(m.forward_logits(x)) for c, m in ms.items()}
+        np.testing.assert_array_equal(np.asarray(ms["bf16_dec_split2"].forward_logits(x)), y["bf16_dec_split2"])
+        e = {c: float(np.abs(v.astype(np.float64) - k[tag]).max()) for c, v in y.items()}
+        print(f"{tag}: max abs err vs the fp64 golden: bf16 {e['bf16']:.2e}, mixed {e['bf16_dec_split2']:.2e}, f32_split2 {e['f32_split2']:.2e}")
+        assert np.isfinite(y["bf16_dec_split2"]).all() and e["bf16_dec_split2"] < BF16_ABS_BOUND["bf16"]
+        feats_mixed = ms["bf16_dec_split2"].backbone.forward(x)
+        for a, b in zip(feats_mixed, ms["bf16"].backbone.forward(x)):
+            np.testing.assert_array_equal(a, b)
+        f32f = ms["f32_split2"].backbone.forward(x)          # any features will do for the decoder-side comparison
+        S = x.shape[-1]
+        fz = [np.concatenate([f, f], 1) for f in f32f[:3]] + [np.random.default_rng(0).standard_normal((x.shape[0], 3072, S // 32, S // 32)).astype(np.float32)]
+        np.testing.assert_array_equal(ms["bf16_dec_split2"].decoder.forward(x, *fz), ms["f32_split2"].decoder.forward(x, *fz))
+        for m in ms.values():
+            m.close()
+    cb2, m = _full_model("bf16_dec_split2", 8, 1024)
+    kk = np.load(os.path.join(GOLD, "model_1024.npz"))
+    xb = torch.from_numpy(cb2.synth_input(8, 1024, 1024)).cuda()
+    yb = m.forward_logits(xb)
+    assert torch.isfinite(yb).all() and torch.equal(yb, m.forward_logits(xb))
+    e0 = float(np.abs(yb.cpu().numpy().astype(np.float64)[0, :, ::16, ::16] - kk["m1024_full_ref_s16"][0]).max())
+    em = _mask_err(m, xb, kk["m1024_full_ref_s16"][0], 16)
+    print(f"c3 [bf16_dec_split2] B=8 1024^2: max abs err of image 0 vs the fp64 golden {e0:.3e} (mask space {em:.3e})")
+    assert em < 1e-3 and e0 < 4e-3
+    m.close()
