@@ -729,6 +729,7 @@ brn_status brn_infer_images_u8(brn_model* mh, int n, const unsigned char* const*
         for (int i = 0; i < n; ++i)
             if (!pixels[i] || !masks[i] || heights[i] < 1 || widths[i] < 1) fail(BRN_ERR_INVALID_ARG, "infer_images: image %d is null or empty", i);
         hipStream_t s = (hipStream_t)stream;
+        std::lock_guard<std::mutex> io_lock(m.io_mu);      // the staging pool and the table cache belong to one call at a time
         auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
         std::vector<size_t> o_raw(n), o_tv(n), o_pv(n), o_out(n);
         size_t total = 0;

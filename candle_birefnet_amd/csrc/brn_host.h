@@ -208,6 +208,7 @@ struct Model {
     // brn_infer_images_u8: device staging of a batch of u8 images + their masks, grown on demand, and the resampling tables by (in, out, filter)
     struct IoPool { char* base = nullptr; size_t cap = 0; };
     IoPool io;
+    std::mutex io_mu;         // brn_infer_images_u8 calls on one handle are serialised end to end (they share the staging pool and the tables)
     struct AxisDev { int in_n, out_n, filter, max_taps; int* left; int* count; float* w; };
     std::vector<AxisDev> axes;
     bool profiling = false;
