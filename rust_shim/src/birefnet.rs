@@ -1,13 +1,14 @@
 //! `BiRefNetConfig` / `BiRefNet` / `SqueezeModule` / `BiRefNetDecoder` of the reference (src/birefnet.rs:13-67, 70-94, 121-377,
 //! 380-476) over `brn_model_*` / `brn_forward*`.  One HBM-resident model handle is shared by the three pub fields the reference
-//! exposes (`backbone`, `squeeze_module`, `decoder`), which examples/bench_inference.rs:34,77,83 drive one by one.
+//! exposes (`backbone`: a `SwinTransformer`, as in the reference; `squeeze_module`; `decoder`), which examples/bench_inference.rs:34,77,83 drive
+//! one by one.
 use std::sync::Arc;
 
 use candle_core::{Module, Result, Tensor};
 use candle_nn::VarBuilder;
 
 use crate::hip_ffi as ffi;
-use crate::swin::{stage_dims, swin_weight_spec, SwinConfig};
+use crate::swin::{swin_weight_spec, SwinConfig, SwinTransformer};
 
 /// BiRefNet configuration — the reference's struct, field for field (birefnet.rs:13-30)
 #[derive(Clone)]
@@ -168,36 +169,8 @@ impl Module for GdtConvs {
     }
 }
 
-// ---- the shared model handle ----
-struct Handle(*mut ffi::BrnModel);
-// forwards on one handle are serialised inside the library (mutex + stream event): safe to share
-unsafe impl Send for Handle {}
-unsafe impl Sync for Handle {}
-impl Drop for Handle {
-    fn drop(&mut self) {
-        unsafe { ffi::brn_model_destroy(self.0) }
-    }
-}
-
-/// `model.backbone` (a SwinTransformer in the reference): forward(x) -> [x1, x2, x3, x4]
-pub struct Backbone {
-    h: Arc<Handle>,
-}
-impl Backbone {
-    pub fn forward(&self, x: &Tensor) -> Result<Vec<Tensor>> {
-        let (b, _c, h, w) = x.dims4()?;
-        let xin = ffi::to_host(x)?;
-        let dims = stage_dims(h, w, 4);
-        let chans = [192usize, 384, 768, 1536];
-        let mut bufs: Vec<Vec<f32>> = (0..4).map(|i| vec![0f32; b * chans[i] * dims[i].0 * dims[i].1]).collect();
-        let ptrs: Vec<*mut f32> = bufs.iter_mut().map(|v| v.as_mut_ptr()).collect();
-        ffi::check(unsafe {
-            ffi::brn_model_backbone_forward(self.h.0, xin.as_ptr(), b as i32, h as i32, w as i32, ffi::BRN_MEM_HOST, ptrs.as_ptr(),
-                                            ffi::BRN_MEM_HOST, std::ptr::null_mut())
-        })?;
-        bufs.into_iter().enumerate().map(|(i, v)| Tensor::from_vec(v, (b, chans[i], dims[i].0, dims[i].1), x.device())).collect()
-    }
-}
+// ---- the shared model handle: hip_ffi::ModelHandle ----
+type Handle = ffi::ModelHandle;
 
 /// Squeeze module (birefnet.rs:70-94): inside a `BiRefNet` it is a view of the shared model handle; built on its own
 /// (`SqueezeModule::new`) it is one `BasicDecBlk` under `vb.pp("0")`, as in the reference
@@ -272,7 +245,7 @@ impl BiRefNetDecoder {
 /// BiRefNet model with Swin Transformer backbone (birefnet.rs:380-385): the same four pub fields
 pub struct BiRefNet {
     pub config: BiRefNetConfig,
-    pub backbone: Backbone,
+    pub backbone: SwinTransformer,
     pub squeeze_module: SqueezeModule,
     pub decoder: BiRefNetDecoder,
     h: Arc<Handle>,
@@ -324,7 +297,7 @@ impl BiRefNet {
     fn wrap(config: BiRefNetConfig, raw: *mut ffi::BrnModel, device: i32) -> Self {
         let h = Arc::new(Handle(raw));
         let out_channels = config.lateral_channels()[3];
-        Self { config, backbone: Backbone { h: h.clone() }, squeeze_module: SqueezeModule { inner: SqueezeImpl::Shared { h: h.clone(), out_channels } }, decoder: BiRefNetDecoder { h: h.clone() }, h, device }
+        Self { config, backbone: SwinTransformer::shared(SwinConfig::swin_l(), h.clone()), squeeze_module: SqueezeModule { inner: SqueezeImpl::Shared { h: h.clone(), out_channels } }, decoder: BiRefNetDecoder { h: h.clone() }, h, device }
     }
 
     /// HIP device ordinal this model's weights and workspace live on

@@ -137,6 +137,17 @@ extern "C" {
                                 mask_out: *mut c_uchar, device_ordinal: c_int, stream: *mut c_void) -> c_int;
 }
 
+/// an HBM-resident model (`brn_model*`) shared by the pieces of a `BiRefNet` (`backbone`, `squeeze_module`, `decoder`); destroyed with
+/// its last owner.  Forwards on one handle are serialised inside the library (mutex + stream event): safe to share between threads.
+pub(crate) struct ModelHandle(pub(crate) *mut BrnModel);
+unsafe impl Send for ModelHandle {}
+unsafe impl Sync for ModelHandle {}
+impl Drop for ModelHandle {
+    fn drop(&mut self) {
+        unsafe { brn_model_destroy(self.0) }
+    }
+}
+
 /// status -> `candle_core::Result`: the message of `brn_last_error()` (thread-local) becomes `candle_core::Error::Msg`, the error
 /// type the reference already returns for its own failures (aspp.rs:101,148).
 pub fn check(status: c_int) -> candle_core::Result<()> {

@@ -141,10 +141,15 @@ impl PatchEmbed {
     }
 }
 
-/// Swin Transformer backbone (swin.rs:718-723); the weights live in HBM behind `handle`
+/// Swin Transformer backbone (swin.rs:718-723).  The weights live in HBM: behind a handle of its own when built by
+/// `SwinTransformer::new`, behind the owning model's handle when it is the `backbone` field of a `BiRefNet` (birefnet.rs:381).
 pub struct SwinTransformer {
     config: SwinConfig,
-    handle: *mut ffi::BrnSwin,
+    inner: SwinImpl,
+}
+enum SwinImpl {
+    Own(*mut ffi::BrnSwin),
+    Model(std::sync::Arc<ffi::ModelHandle>),
 }
 // the library serialises calls on one handle with an internal mutex
 unsafe impl Send for SwinTransformer {}
@@ -160,7 +165,12 @@ impl SwinTransformer {
         let mut handle = std::ptr::null_mut();
         let empty = std::ffi::CString::new("").unwrap();
         ffi::check(unsafe { ffi::brn_swin_create(&c, named.views.as_ptr(), named.views.len(), empty.as_ptr(), 0, &mut handle) })?;
-        Ok(Self { config, handle })
+        Ok(Self { config, inner: SwinImpl::Own(handle) })
+    }
+
+    /// the backbone of a whole model (the `backbone` pub field of `BiRefNet`): no weights of its own
+    pub(crate) fn shared(config: SwinConfig, model: std::sync::Arc<ffi::ModelHandle>) -> Self {
+        Self { config, inner: SwinImpl::Model(model) }
     }
 
     /// swin.rs:768 — x [B, in_channels, H, W] -> [x1, x2, x3, x4], each [B, C_i, H_i, W_i]
@@ -175,8 +185,12 @@ impl SwinTransformer {
         let mut bufs: Vec<Vec<f32>> = (0..4).map(|i| vec![0f32; b * chans[i] * dims[i].0 * dims[i].1]).collect();
         let ptrs: Vec<*mut f32> = bufs.iter_mut().map(|v| v.as_mut_ptr()).collect();
         ffi::check(unsafe {
-            ffi::brn_swin_forward(self.handle, xin.as_ptr(), b as i32, h as i32, w as i32, ffi::BRN_MEM_HOST, ptrs.as_ptr(), ffi::BRN_MEM_HOST,
-                                  std::ptr::null_mut())
+            match &self.inner {
+                SwinImpl::Own(handle) => ffi::brn_swin_forward(*handle, xin.as_ptr(), b as i32, h as i32, w as i32, ffi::BRN_MEM_HOST, ptrs.as_ptr(),
+                                                               ffi::BRN_MEM_HOST, std::ptr::null_mut()),
+                SwinImpl::Model(m) => ffi::brn_model_backbone_forward(m.0, xin.as_ptr(), b as i32, h as i32, w as i32, ffi::BRN_MEM_HOST, ptrs.as_ptr(),
+                                                                      ffi::BRN_MEM_HOST, std::ptr::null_mut()),
+            }
         })?;
         bufs.into_iter().enumerate().map(|(i, v)| Tensor::from_vec(v, (b, chans[i], dims[i].0, dims[i].1), x.device())).collect()
     }
@@ -184,6 +198,8 @@ impl SwinTransformer {
 
 impl Drop for SwinTransformer {
     fn drop(&mut self) {
-        unsafe { ffi::brn_swin_destroy(self.handle) }
+        if let SwinImpl::Own(handle) = self.inner {
+            unsafe { ffi::brn_swin_destroy(handle) }
+        }
     }
 }

@@ -160,7 +160,7 @@ def main():
         ("birefnet.rs", "birefnet.rs:97-118", [r"pub struct GdtConvs", r"impl GdtConvs \{.*?pub fn new\(in_channels: usize, vb: VarBuilder\)", r"impl Module for GdtConvs"]),
         ("birefnet.rs", "birefnet.rs:121-377", [r"pub struct BiRefNetDecoder", r"impl BiRefNetDecoder \{.*?pub fn new\(config: BiRefNetConfig, vb: VarBuilder\)",
                                                 r"pub fn forward\(&self, x: &Tensor, x1: &Tensor, x2: &Tensor, x3: &Tensor, x4: &Tensor\) -> Result<Tensor>"]),
-        ("birefnet.rs", "birefnet.rs:380-476", [r"pub struct BiRefNet \{", r"pub config: BiRefNetConfig", r"pub backbone:", r"pub squeeze_module: SqueezeModule", r"pub decoder: BiRefNetDecoder",
+        ("birefnet.rs", "birefnet.rs:380-476", [r"pub struct BiRefNet \{", r"pub config: BiRefNetConfig", r"pub backbone: SwinTransformer", r"pub squeeze_module: SqueezeModule", r"pub decoder: BiRefNetDecoder",
                                                 r"pub fn new\(config: BiRefNetConfig, vb: VarBuilder\) -> Result<Self>", r"pub fn forward_logits\(&self, x: &Tensor\) -> Result<Tensor>",
                                                 r"pub fn forward\(&self, x: &Tensor\) -> Result<Tensor>", r"impl Module for BiRefNet"]),
         ("decoder.rs", "decoder.rs:12-24", [r"pub struct DecoderConfig", r"pub use_aspp_deformable: bool", r"pub inter_channels_adaptive: bool", r"impl Default for DecoderConfig"]),
