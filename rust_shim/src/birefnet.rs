@@ -227,7 +227,7 @@ impl BiRefNetDecoder {
         ffi::check(unsafe {
             ffi::brn_decoder_create(&c, named.views.as_ptr(), named.views.len(), prefix.as_ptr(), device_from_env(), compute_from_env(), &mut raw)
         })?;
-        Ok(Self { h: Arc::new(Handle(raw)) })
+        Ok(Self { h: Arc::new(ffi::ModelHandle(raw)) })
     }
     /// birefnet.rs:278 — same signature
     pub fn forward(&self, x: &Tensor, x1: &Tensor, x2: &Tensor, x3: &Tensor, x4: &Tensor) -> Result<Tensor> {
@@ -295,7 +295,7 @@ impl BiRefNet {
     }
 
     fn wrap(config: BiRefNetConfig, raw: *mut ffi::BrnModel, device: i32) -> Self {
-        let h = Arc::new(Handle(raw));
+        let h = Arc::new(ffi::ModelHandle(raw));
         let out_channels = config.lateral_channels()[3];
         Self { config, backbone: SwinTransformer::shared(SwinConfig::swin_l(), h.clone()), squeeze_module: SqueezeModule { inner: SqueezeImpl::Shared { h: h.clone(), out_channels } }, decoder: BiRefNetDecoder { h: h.clone() }, h, device }
     }
