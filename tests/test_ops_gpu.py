@@ -429,7 +429,8 @@ def test_window_attention_bf16_two_heads_per_workgroup(gpu, tmp_path):
 def test_short_k_weight_stationary_gemm_bf16_mode(gpu, C, H, W, O, act):
     """gemm_wstat_bf16_kernel (K = 192 with 64-row tiles, K = 384 with 32-row tiles; N % 192 == 0, M >= 32768: the stage-0 / stage-1
     qkv and fc1 GEMMs at batch >= 4) through a 1x1 conv on a bf16 map: full and ragged row tiles (M % 64, M % 32 != 0), 1 ... 8 column
-    groups, bias, GELU / ReLU.  Exact-operand reference; the output map is bf16: one bf16 ulp (+ the 3-term erfc's 2.6e-5 for GELU)."""
+    groups, bias, GELU / ReLU.  Exact-operand reference; the output map is bf16: one bf16 ulp + 1e-5 (fp32 accumulation; the bf16-output
+    GELU, 2^P(|x|) with P of degree 5, is within 3e-6 of erf-GELU: the erfc series it replaced needed 4e-5 here)."""
     from candle_birefnet_amd import ops
     x, w, b = rnd(1, C, H, W, seed=1), rnd(O, C, 1, 1, seed=2, std=C ** -0.5), rnd(O, seed=3, std=0.1)
     ops.set_compute("bf16")
@@ -442,7 +443,7 @@ def test_short_k_weight_stationary_gemm_bf16_mode(gpu, C, H, W, O, act):
     ref = F.conv2d(torch.from_numpy(_bf16_round(x)), torch.from_numpy(_bf16_round(w)), torch.from_numpy(b).double())
     ref = (F.gelu(ref) if act == "gelu_erf" else F.relu(ref) if act == "relu" else ref).numpy()
     err = np.abs(np.asarray(y, np.float64) - ref)
-    assert (err <= 2.0 ** -8 * np.abs(ref) + 4e-5).all(), f"max abs err {err.max():.3e}"
+    assert (err <= 2.0 ** -8 * np.abs(ref) + 1e-5).all(), f"max abs err {err.max():.3e}"
 
 
 def test_conv2d_nan_stays_local(gpu):
