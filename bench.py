@@ -44,6 +44,8 @@ MODES = {
     "f32": (0, "f32 (v_mfma_f32_32x32x2_f32, exact fp32 operands)", 4),
     "f32_split3": (6, "f32 storage+accumulate; GEMM operands split error-free into 3 bf16 terms, 6 bf16 MFMAs/product (fp32-equivalent)", 4),
     "f32_split2": (3, "f32 storage+accumulate; GEMM operands split into 2 bf16 terms (16-bit mantissa), 3 bf16 MFMAs/product", 4),
+    "f32_half2": (3, "f32 storage+accumulate; GEMM operands as two fp16 planes of the power-of-two-scaled operand (22-bit mantissa), 3 fp16 MFMAs/product "
+                     "(fp32-equivalent inside the fp16 range: |GEMM input| < 8190)", 4),
     "bf16": (1, "bf16 (activations and weights stored bf16 in HBM, bf16 MFMA, f32 accumulate / LayerNorm / softmax statistics)", 2),
     "bf16_dec_split2": (1, "mixed: Swin backbone as bf16 (79 % of the FLOPs), fusion / squeeze / decoder as f32_split2 on f32 maps (3 bf16 MFMAs / product); "
                            "roofline priced against the bf16 peak", 2),
@@ -107,7 +109,7 @@ def parse_args(argv=None):
     ap.add_argument("--compute", default="", choices=[""] + list(MODES),
                     help="arithmetic of the contraction kernels (include/birefnet_hip.h brn_dtype; overrides --config)")
     ap.add_argument("--strong", action="store_true", help="strong scaling: the config's 8-GPU global batch (images/GPU x 8) is split over the ranks")
-    ap.add_argument("--also", default=None, help="comma list of other compute modes to time briefly on rank 0 at N=1 ('' = none; default: f32_split2,f32 for c2)")
+    ap.add_argument("--also", default=None, help="comma list of other compute modes to time briefly on rank 0 at N=1 ('' = none; default: f32_half2,f32_split2,f32 for c2)")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra steps with per-launch HIP events for the roofline block")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off", "on"])
     ap.add_argument("--other-configs", default="auto", choices=["auto", "off", "on"],
@@ -256,7 +258,7 @@ def roofline_block(fam, n, compute, traffic_key, quote_traffic):
         "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
         "peak_note": ("fp32 MFMA dense peak" if npairs == 0 else
                       "bf16 MFMA dense peak" if npairs == 1 else
-                      f"bf16 MFMA dense peak 2500 / {npairs} MFMAs per fp32 product; achieved counts ALGORITHMIC 2*M*N*K "
+                      f"{'fp16' if compute == 'f32_half2' else 'bf16'} MFMA dense peak 2500 / {npairs} MFMAs per fp32 product; achieved counts ALGORITHMIC 2*M*N*K "
                       f"(= {achieved / PEAK_F32_MFMA_TFLOPS:.2f}x the fp32-MFMA peak of {PEAK_F32_MFMA_TFLOPS})"),
         "launches_per_step": launches // n, "gflop_per_step": round(fl / n / 1e9, 1), "ms_per_step": round(ms / n, 3),
         "avg_launch_ms": round(ms / max(1, launches), 4),
@@ -307,7 +309,7 @@ def main(argv=None):
         B, scaling = gb // world, "strong"
     custom = (B, S, compute) != (cB, cS, cmode) and not args.strong
     default_line = args.config == "c2" and not custom and not args.strong and args.deform_mode == "reference_cpu"
-    also = args.also if args.also is not None else ("f32_split2,f32" if (args.config == "c2" and not custom) else "")
+    also = args.also if args.also is not None else ("f32_half2,f32_split2,f32" if (args.config == "c2" and not custom) else "")
     others_on = args.other_configs == "on" or (args.other_configs == "auto" and default_line)
 
     import numpy as np

@@ -344,7 +344,7 @@ const char* brn_last_error(void) { return last_error_cstr(); }
 const char* brn_build_info(void) {
 #define BRN_STR2(x) #x
 #define BRN_STR(x) BRN_STR2(x)
-    return "libbirefnet_hip gfx950 (CDNA4): compute modes f32 (fp32 MFMA), f32_split3 / f32_split2 (split-bf16 MFMA, fp32 storage), bf16 (bf16 storage + MFMA); HIP " BRN_STR(HIP_VERSION_MAJOR) "." BRN_STR(HIP_VERSION_MINOR) "." BRN_STR(HIP_VERSION_PATCH);
+    return "libbirefnet_hip gfx950 (CDNA4): compute modes f32 (fp32 MFMA), f32_split3 / f32_split2 (split-bf16 MFMA, fp32 storage), f32_half2 (fp16-pair MFMA, fp32 storage), bf16 (bf16 storage + MFMA); HIP " BRN_STR(HIP_VERSION_MAJOR) "." BRN_STR(HIP_VERSION_MINOR) "." BRN_STR(HIP_VERSION_PATCH);
 }
 brn_status brn_device_count(int* n) {
     return guarded([&] {
@@ -388,6 +388,7 @@ brn_status brn_model_create(const brn_config* cfg, const brn_named_tensor* weigh
         if (dt == BRN_F32) planes = 0;
         else if (dt == BRN_F32_SPLIT3) planes = 3;
         else if (dt == BRN_F32_SPLIT2) planes = 2;
+        else if (dt == BRN_F32_HALF2) planes = BUILD_HALF2;
 #ifdef BRN_DIAG_BUILD
         else if (dt == BRN_BF16_OPERANDS) planes = 1;
 #else
@@ -424,6 +425,7 @@ brn_status brn_decoder_create(const brn_config* cfg, const brn_named_tensor* wei
         if (dt == BRN_F32) planes = 0;
         else if (dt == BRN_F32_SPLIT3) planes = 3;
         else if (dt == BRN_F32_SPLIT2) planes = 2;
+        else if (dt == BRN_F32_HALF2) planes = BUILD_HALF2;
         else if (dt == BRN_BF16) planes = BUILD_BF16;
         else if (dt == BRN_BF16_DEC_SPLIT2) planes = 2;                                    // (a decoder on its own in the mixed mode = mode f32_split2)
         else fail(BRN_ERR_INVALID_ARG, "unsupported compute dtype %d", (int)dt);
@@ -796,6 +798,7 @@ brn_status brn_set_op_compute(int dtype) {
         if (dtype == BRN_F32) g_op_planes = 0;
         else if (dtype == BRN_F32_SPLIT3) g_op_planes = 3;
         else if (dtype == BRN_F32_SPLIT2) g_op_planes = 2;
+        else if (dtype == BRN_F32_HALF2) g_op_planes = BUILD_HALF2;
 #ifdef BRN_DIAG_BUILD
         else if (dtype == BRN_BF16_OPERANDS) g_op_planes = 1;
 #else

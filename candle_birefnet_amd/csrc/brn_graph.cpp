@@ -89,6 +89,8 @@ struct ArenaHold {
 static void fill_epilogue(GemmParams& p, const GemmW& w) {
     p.bias = w.bias; p.scale = w.scale; p.shift = w.shift; p.act = w.act;
     p.Wp = w.wp; p.planes = w.planes; p.wp_rows = w.wp_rows;
+    p.h2 = w.half;
+    if (w.half) { p.a_scale = half2_act_scale(); p.out_scale = 1.f / (p.a_scale * w.w_scale); }
 }
 
 // bf16-storage mode: the same GEMM on kernels/gemm_bf16.hip (A bf16; C / R bf16 unless flagged fp32)
@@ -285,6 +287,7 @@ void run_layernorm(Ctx& c, const LNW& ln, const float* x, int rows, int ldx, flo
     LayerNormParams p{};
     p.x = x; p.y = y; p.rows = rows; p.C = ln.C; p.gamma = ln.g; p.beta = ln.b; p.eps = 1e-5f;
     p.ldx = ldx; p.ldy = ldy; p.y_coff = y_coff; p.mode = 0; p.y_planes = y_planes; p.y_bf16 = y_bf16;
+    p.y_h2 = y_planes == 2 ? c.h2_scale : 0.f;
     Bracket b(c, FAM_LAYERNORM, 0.0, (y_bf16 ? 6.0 : 8.0) * rows * (double)ln.C, rows, ln.C, 0);
     BRN_LAUNCH(launch_layernorm(p, c.stream));
 }
@@ -374,8 +377,9 @@ static bool swin_attention_multi(Ctx& c, const SwinBlockW& blk, const float* xn,
             p.Hp = roundup(hs[k], window); p.Wp = roundup(wsz[k], window);   // swin.rs:359-360
             p.ws = window;
             p.shift = shift; p.scale = 1.0f / sqrtf(32.0f);          // head_dim^-0.5 (swin.rs:134)
-            p.planes = (!c.bf16 && window == 12 && (blk.qkv.planes == 2 || blk.qkv.planes == 1)) ? blk.qkv.planes : 0;
+            p.planes = (!c.bf16 && !blk.qkv.half && window == 12 && (blk.qkv.planes == 2 || blk.qkv.planes == 1)) ? blk.qkv.planes : 0;   // (f32_half2: the fp32-MFMA kernel, like f32_split3)
             p.out_planes = p2;
+            p.out_h2 = (p2 == 2 && blk.qkv.half) ? c.h2_scale : 0.f;
             nwin += (double)B * (p.Hp / window) * (p.Wp / window) * blk.heads;
             off += (size_t)B * hs[k] * wsz[k];
         }
@@ -468,6 +472,7 @@ void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int 
             if (w.window == 12 && (np == 2 || (np == 3 && planes_on)) && b0.qkv.wp && b0.proj.wp && b0.fc1.wp && b0.fc2.wp && C % 32 == 0 && hidden % 32 == 0) stage_pl = np;
         }
         const int ldx = stage_pl ? C * stage_pl / 2 : C, ldh = stage_pl ? hidden * stage_pl / 2 : hidden;
+        c.h2_scale = (stage_pl == 2 && st.blocks[0].qkv.half) ? half2_act_scale() : 0.f;    // mode f32_half2: the P2 planes are fp16 planes of the scaled activations
         // compute mode BRN_BF16: x (the residual stream) stays fp32; every GEMM operand (xn, qkv, att, hid, pm) is bf16
         const int yb = c.bf16;
         const bool xn_ready = i == 0 && xn0 && !stage_pl && ldx == C;     // block 0's norm1 came out of the PatchEmbed kernel
@@ -503,6 +508,7 @@ void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int 
                     p.x = x + off * C; p.y = c.at(pm, off2 * ldpm); p.rows = M2; p.y_bf16 = yb; p.C = 4 * C; p.gamma = st.down_norm.g; p.beta = st.down_norm.b;
                     p.eps = 1e-5f; p.ldy = ldpm; p.y_coff = 0; p.mode = 1; p.H = hh[k]; p.W = ww[k]; p.Cin = C;
                     p.y_planes = pm_pl;                                            // P layout for the reduction GEMM
+                    p.y_h2 = (pm_pl == 2 && st.reduction.half) ? half2_act_scale() : 0.f;
                     Bracket b(c, FAM_LAYERNORM, 0.0, 8.0 * M2 * 4.0 * C, M2, 4 * C, 1);
                     BRN_LAUNCH(launch_layernorm(p, c.stream));
                 }
@@ -511,6 +517,7 @@ void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int 
             off += rows(k, i);
         }
         if (st.has_down) run_gemm(c, st.reduction, pm, total(i + 1), ldpm, xnext, 2 * C, 0, nullptr, 0, 0, nullptr, 0, pm_pl, 0, yb, 0);
+        c.h2_scale = 0.f;
         c.arena->release(mk);
         x = xnext;
     }

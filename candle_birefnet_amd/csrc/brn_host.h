@@ -72,6 +72,7 @@ struct Ctx {
     std::vector<hipEvent_t>* event_pool; size_t* event_next;
     // compute mode BRN_BF16: activation maps are bf16 in HBM (esz = 2); pointers stay typed float* and are opaque to the host
     bool bf16 = false;
+    float h2_scale = 0.f;   // > 0 inside a Swin stage of mode f32_half2: P2-layout producers write fp16 planes of h2_scale * x (kernels/split_planes.h)
     int region = REGION_NONE;       // tag of the launches being recorded (profiling only)
     BranchSet* br = nullptr;        // null: every branch stays on `stream` (profiled forwards, the op-level entry points)
     unsigned pending = 0;           // branches enqueued on aux streams and not yet joined (bit k = aux stream k)
@@ -97,6 +98,8 @@ struct GemmW {          // one Linear / Conv2d, repacked for gemm_f32
     float* w = nullptr; // [roundup(N,128)][K]
     void* wp = nullptr; // split-bf16 path: [planes][roundup(N,128)][K] bf16 planes of the same matrix (or null)
     int planes = 0, wp_rows = 0;
+    int half = 0;       // mode f32_half2: wp = two fp16 planes of w_scale * W (w_scale a power of two chosen per tensor: max |w| w_scale in (2^13, 2^14])
+    float w_scale = 1.f;
     void* wb = nullptr; // bf16-storage mode (BRN_BF16): plain [wb_rows][wb_ld] bf16, rows padded to 256, K padded to 64 (zeros)
     int wb_rows = 0, wb_ld = 0;
     int wb_chunk_major = 0;   // wb's K order is (64-channel chunk, tap, channel in chunk) (channels-last convs with Cinp % 64 == 0, Cinp > 64: gemm_bf16.hip)
@@ -287,6 +290,8 @@ void ensure_device(int ordinal);
 // number of bf16 planes the weight builders attach to every dense / channels-last conv GemmW (0 = fp32 MFMA path only);
 // BUILD_BF16: attach the plain bf16 matrix of the bf16-storage mode instead
 constexpr int BUILD_BF16 = 16;
+constexpr int BUILD_HALF2 = 18;   // two fp16 planes of the scaled matrix (mode f32_half2)
+float half2_act_scale();          // the power of two GEMM activations are scaled by before the fp16 split (BRN_H2_ASCALE, default 8)
 void set_build_planes(int planes);
 int build_planes();
 

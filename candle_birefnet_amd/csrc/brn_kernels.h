@@ -43,6 +43,10 @@ struct GemmParams {
     // split-K (filled by launch_gemm from the plan): slices write raw partials to part[slice][M][N]
     int splitk; float* part;
     int a_planes, c_planes;   // 2: A is read / C is written in the P2 layout (kernels/split_planes.h); split-bf16 dense ws kernel only
+    // mode f32_half2 (planes == 2 with fp16 planes, kernels/split_planes.h: split4h): Wp holds the fp16 planes of w_scale * W (a power of two per
+    // tensor, GemmW::w_scale), A is split as the fp16 planes of a_scale * A while it is staged, and the accumulators are multiplied by
+    // out_scale = 1 / (a_scale * w_scale) — exact — before the epilogue
+    int h2; float a_scale, out_scale;
     // bf16-storage mode (kernels/gemm_bf16.hip): A, C, R are bf16 unless flagged; Wp is the plain [wp_rows][wp_ld] bf16 matrix
     int wp_ld;                // elements per W row (K rounded up to 64, zero padded)
     int k_chunk_major;        // bf16 implicit GEMM: W's K order is (64-channel chunk, tap, channel in chunk) instead of (tap, channel); Cin % 64 == 0
@@ -109,6 +113,7 @@ struct LayerNormParams {
     // (2i,2j),(2i+1,2j),(2i,2j+1),(2i+1,2j+1) of x [B,H,W,Cin], zero outside (odd H/W padding), C == 4*Cin
     int mode; int H, W, Cin;
     int y_planes;         // 2: write y in the P2 layout (kernels/split_planes.h) for a split-bf16 GEMM; 0: fp32
+    float y_h2;           // > 0 (with y_planes == 2): the planes are the fp16 planes of y_h2 * y (mode f32_half2)
     int y_bf16;           // 1: y is a bf16 matrix (compute mode BRN_BF16; x stays fp32: the residual stream)
 };
 hipError_t launch_layernorm(const LayerNormParams& p, hipStream_t s);
@@ -124,6 +129,7 @@ struct WindowAttnParams {
     float scale;          // head_dim^-0.5
     int planes;           // 0: fp32 MFMA kernel (modes f32, f32_split3); 2 / 1: bf16-split kernel (f32_split2 / bf16_operands)
     int out_planes;       // 2: write `out` in the P2 layout (kernels/split_planes.h) for the proj GEMM; 0: fp32
+    float out_h2;         // > 0 (with out_planes == 2, planes == 0): fp16 planes of out_h2 * out (mode f32_half2, written by the fp32-MFMA kernel)
     int ws;               // window side: 12 (0 = 12) or 7 (Swin-T / S: fp32 kernel only)
     int io_bf16;          // 1: qkv and out are bf16 matrices (compute mode BRN_BF16; qkv_bias / rel_table stay fp32)
 };

@@ -86,6 +86,40 @@ static inline float bf16_to_f32(uint16_t h) {
     memcpy(&f, &u, 4);
     return f;
 }
+static inline uint16_t f16_rne(float x) {             // round-to-nearest-even fp32 -> fp16 (finite inputs; |x| >= 65520 -> Inf)
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+    u &= 0x7fffffffu;
+    if (u >= 0x47800000u) return sign | 0x7c00u;
+    if (u < 0x38800000u) {                             // below 2^-14: a multiple of 2^-24 — the ulp of fp32 numbers in [0.5, 1)
+        float f;
+        memcpy(&f, &u, 4);
+        f += 0.5f;
+        uint32_t v;
+        memcpy(&v, &f, 4);
+        return sign | (uint16_t)(v - 0x3f000000u);
+    }
+    uint32_t v = u - 0x38000000u;
+    v += 0xfffu + ((v >> 13) & 1u);
+    return sign | (uint16_t)(v >> 13);
+}
+static inline float f16_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3ffu;
+    float f;
+    if (e == 0) { f = (float)m * 5.9604644775390625e-08f; uint32_t u; memcpy(&u, &f, 4); u |= sign; memcpy(&f, &u, 4); return f; }
+    const uint32_t u = sign | ((e == 31 ? 255u : e + 112u) << 23) | (m << 13);
+    memcpy(&f, &u, 4);
+    return f;
+}
+float half2_act_scale() {
+    static const float s = [] {
+        const char* e = getenv("BRN_H2_ASCALE");
+        const int k = e ? atoi(e) : 3;                  // log2 of the scale
+        return ldexpf(1.f, k < 0 ? 0 : (k > 8 ? 8 : k));
+    }();
+    return s;
+}
 // error-free split of the packed fp32 matrix [rows][K] into bf16 planes: plane p = RN_bf16(x - sum of the previous planes),
 // stored interleaved per 32-deep K tile: [row][K/32][plane][32] (a (row, K tile) is NP x 64 contiguous bytes)
 static void attach_planes(DeviceOwner& own, GemmW& g, const std::vector<float>& pk, int rows) {
@@ -119,6 +153,32 @@ static void attach_planes(DeviceOwner& own, GemmW& g, const std::vector<float>& 
     }
     const size_t n = pk.size();
     const size_t K = (size_t)g.K;
+    if (np == BUILD_HALF2) {
+        // mode f32_half2: hi = RN_f16(s w), lo = RN_f16(s w - hi), s = 2^k with max |w| s in (2^13, 2^14] — both planes of every weight that
+        // matters are normal fp16 numbers (hi + lo = s w up to 2^-22), and what falls below 2^-14 is 2^-38 of the largest weight
+        float mx = 0.f;
+        for (size_t i = 0; i < n; ++i) mx = std::max(mx, fabsf(pk[i]));
+        int k = 0;
+        if (mx > 0.f && std::isfinite(mx)) { int ex; frexpf(mx, &ex); k = 14 - ex; }     // mx = f 2^ex, f in [0.5, 1): mx 2^k in [2^13, 2^14)
+        k = std::max(-100, std::min(100, k));
+        const float sc = ldexpf(1.f, k);
+        std::vector<uint16_t> planes(n * 2);
+        for (size_t i = 0; i < n; ++i) {
+            const size_t row = i / K, kk = i - row * K;
+            const float x = pk[i] * sc;
+            const uint16_t h = f16_rne(x), l = f16_rne(x - f16_to_f32(h));
+            const size_t o = (row * (K / 32) + kk / 32) * (size_t)64 + (kk & 31);
+            planes[o] = h;
+            planes[o + 32] = l;
+        }
+        void* d = nullptr;
+        hipError_t e = hipMalloc(&d, planes.size() * 2 + 16);
+        if (e != hipSuccess) fail(BRN_ERR_OOM, "hipMalloc of %zu bytes failed: %s", planes.size() * 2, hipGetErrorString(e));
+        own.ptrs.push_back(d);
+        BRN_HIP(hipMemcpy(d, planes.data(), planes.size() * 2, hipMemcpyHostToDevice));
+        g.wp = d; g.planes = 2; g.wp_rows = rows; g.half = 1; g.w_scale = sc;
+        return;
+    }
     std::vector<uint16_t> planes(n * np);
     for (size_t i = 0; i < n; ++i) {
         const size_t row = i / K, k = i - row * K;

@@ -129,6 +129,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                 const int m = m0 + wm * WTM + i * 32 + row;
                 f32x4 v = *reinterpret_cast<const f32x4*>(patch + row * EPI_LD + c4);
                 if (m >= p.M || n >= p.N) continue;
+                if (p.h2) v = v * p.out_scale;           // mode f32_half2: the operands were scaled by powers of two (exact)
                 if (split) {
                     float* dst = part + (long)m * p.N + n;
                     if (vec) *reinterpret_cast<f32x4*>(dst) = v;
@@ -407,8 +408,9 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_f32_kernel(const GemmParams 
 // =====================================================================================================================
 constexpr int SLD = 40;   // bf16 elements per LDS row
 
-template <int BM, int BN, int WM, int WN, int MODE, int NP>
+template <int BM, int BN, int WM, int WN, int MODE, int NP, bool H = false>   // H: the two planes are fp16 (mode f32_half2)
 __global__ void __launch_bounds__(WM* WN * 64) gemm_split_kernel(const GemmParams p) {
+    static_assert(!H || NP == 2, "fp16 planes come in pairs");
     constexpr int NT = WM * WN * 64;
     constexpr int RPP = NT / 8;           // A rows per pass (8 float4 per 32-float row)
     constexpr int PA = BM / RPP;
@@ -500,7 +502,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_split_kernel(const GemmParam
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             bf16x4 sp[NP];
-            split4<NP>(qa[i], qm[i], sp);
+            if constexpr (H) split4h<true>(qa[i], qm[i], p.a_scale, sp); else split4<NP>(qa[i], qm[i], sp);
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
                 *reinterpret_cast<bf16x4*>(As + (pl * BM + lrow + i * RPP) * SLD + kq * 4) = sp[pl];
@@ -549,7 +551,8 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_split_kernel(const GemmParam
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa][i], bf[pb][j], acc[i][j], 0, 0, 0);
+                            if constexpr (H) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[pa][i]), __builtin_bit_cast(f16x8, bf[pb][j]), acc[i][j], 0, 0, 0);
+                            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa][i], bf[pb][j], acc[i][j], 0, 0, 0);
                 }
         }
     };
@@ -607,6 +610,7 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, const fl
         const int m = m0 + row;
         if (m >= p.M) break;
         f32x4 v = *reinterpret_cast<const f32x4*>(ctile + row * LD + c4);
+        if (p.h2) v = v * p.out_scale;
         if (split) {
             float* dst = part + (long)m * p.N + n;
             if (vec) *reinterpret_cast<f32x4*>(dst) = v;
@@ -629,7 +633,8 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, const fl
         v = act4(v, p.act);
         float* dst = p.C + (long)m * p.ldc + p.c_coff + n;
         if (p.c_planes) {                   // the next GEMM reads the P layout (launch_gemm checked N, c_coff % 32 == 0, no R)
-            store_planes_n(p.c_planes, p.C + (long)m * p.ldc, p.c_coff + n, v);
+            if (p.h2) store_planes_h(p.C + (long)m * p.ldc, p.c_coff + n, v, p.a_scale);     // (the next GEMM's A scale is this one's: one scale per model)
+            else store_planes_n(p.c_planes, p.C + (long)m * p.ldc, p.c_coff + n, v);
         } else if (vec) {
             if (p.R) v = v + *reinterpret_cast<const f32x4*>(p.R + (long)m * p.ldr + p.r_coff + n);
             *reinterpret_cast<f32x4*>(dst) = v;
@@ -655,12 +660,14 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, const fl
 // registers: at bf16 MFMA rates an exposed LDS read (~250 cycles) per 32-deep K tile (768 MFMA cycles) was a third of the
 // loop (measured by ablation: staging and MFMA phases added up, then the fragment-read stall did).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int MODE, int NP, int KS, bool DIAG, bool APL>   // APL: A arrives in the P2 layout (its producer already split it): the staging waves only copy
+template <int MODE, int NP, int KS, bool DIAG, bool APL, bool H = false>   // APL: A arrives in the P2 layout (its producer already split it): the staging waves only copy
+// H: the two planes are fp16 planes of the scaled operands (mode f32_half2; split4h / v_mfma_f32_32x32x16_f16), same bytes and layouts
 // DIAG: ablation switches + per-K-tile cycle stamps (brn_gemm_microbench only; costs registers)
 // KS = k elements per LDS stage (32, or 16 to halve the stage when 3 planes must fit twice per CU)
 __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) {
     constexpr int BM = 128, BN = 128, WTM = 64, WTN = 64, TM = 2, TN = 2;
     static_assert(!APL || ((NP == 2 || NP == 3) && MODE == GEMM_DENSE), "the P input layout is the NP-plane split of a dense A");
+    static_assert(!H || NP == 2, "fp16 planes come in pairs");
     // LDS rows (round 4): UNPADDED KS-element rows with the 16-byte chunks of a row XOR-permuted by the row — key (row >> 3) & 1 for the
     // 32-byte rows of a 16-deep stage (8 rows per 256-byte bank row), (row >> 2) & 3 for 64-byte rows (4 per bank row).  A ds_read_b128
     // lane group (16 consecutive rows, one logical chunk) then touches 16 different 16-byte slots, AND a producer store instruction
@@ -880,7 +887,8 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
 #pragma unroll
             for (int i = 0; i < PA; ++i) {
                 bf16x4 sp[NP];
-                if (BUFA || (BUFC && bufc_ok)) split4<NP, false>(qa[i], qm[i], sp); else split4<NP>(qa[i], qm[i], sp);
+                if constexpr (H) { if (BUFA || (BUFC && bufc_ok)) split4h<false>(qa[i], qm[i], p.a_scale, sp); else split4h<true>(qa[i], qm[i], p.a_scale, sp); }
+                else if (BUFA || (BUFC && bufc_ok)) split4<NP, false>(qa[i], qm[i], sp); else split4<NP>(qa[i], qm[i], sp);
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl)
                     *reinterpret_cast<bf16x4*>(As + (pl * BM + lrow + i * RPP) * SLD + a_sw) = sp[pl];
@@ -960,7 +968,8 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[pb][j], af[pa][i], acc[i][j], 0, 0, 0);   // transposed product: see the C tile image below
+                        if constexpr (H) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf[pb][j]), __builtin_bit_cast(f16x8, af[pa][i]), acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[pb][j], af[pa][i], acc[i][j], 0, 0, 0);   // transposed product: see the C tile image below
             }
     };
     bf16x8 fa0[NP][TM], fb0[NP][TN], fa1[NP][TM], fb1[NP][TN];
@@ -1014,6 +1023,18 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
 template <int NP, int KS>
 static hipError_t launch_split_ws_ks(const GemmParams& p, dim3 grid, hipStream_t s) {
     const dim3 block(512);
+    if (p.h2) {                           // mode f32_half2: two fp16 planes, 32-deep stages, plain or P-layout A
+        if constexpr (NP == 2 && KS == 32) {
+            if (p.a_planes) {
+                if (p.mode != GEMM_DENSE || p.a_planes != 2) return hipErrorInvalidValue;
+                hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, 2, 32, false, true, true>), grid, block, 0, s, p);
+            } else if (p.mode == GEMM_DENSE) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_DENSE, 2, 32, false, false, true>), grid, block, 0, s, p);
+            else if (p.mode == GEMM_CONV_NHWC) hipLaunchKernelGGL((gemm_split_ws_kernel<GEMM_CONV_NHWC, 2, 32, false, false, true>), grid, block, 0, s, p);
+            else return hipErrorInvalidValue;
+            return hipGetLastError();
+        }
+        return hipErrorInvalidValue;
+    }
     if (p.a_planes) {
         if constexpr (NP == 2 && KS == 32) {   // (the 3-plane form works too, but was 2 % slower per forward: rows 1.5x as long)
             if (p.mode != GEMM_DENSE || p.a_planes != NP) return hipErrorInvalidValue;
@@ -1047,6 +1068,15 @@ template <int BM, int BN, int WM, int WN, int NP>
 static hipError_t launch_split_cfg(const GemmParams& p, hipStream_t s) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.splitk;
     dim3 grid(tiles), block(WM * WN * 64);
+    if (p.h2) {
+        if constexpr (NP == 2) {
+            if (p.mode == GEMM_DENSE) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WM, WN, GEMM_DENSE, 2, true>), grid, block, 0, s, p);
+            else if (p.mode == GEMM_CONV_NHWC) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WM, WN, GEMM_CONV_NHWC, 2, true>), grid, block, 0, s, p);
+            else return hipErrorInvalidValue;
+            return hipGetLastError();
+        }
+        return hipErrorInvalidValue;
+    }
     if (p.mode == GEMM_DENSE) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WM, WN, GEMM_DENSE, NP>), grid, block, 0, s, p);
     else if (p.mode == GEMM_CONV_NHWC) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WM, WN, GEMM_CONV_NHWC, NP>), grid, block, 0, s, p);
     else return hipErrorInvalidValue;
@@ -1368,6 +1398,8 @@ hipError_t launch_gemm(const GemmParams& p_in, const GemmPlan& pl, float* ws, hi
     if (p.splitk > 1 && !ws) return hipErrorInvalidValue;
     if (p.a_bf16 && p.mode != GEMM_DEFORM_NHWC) return hipErrorInvalidValue;       // only the deformable loader reads bf16 maps here
     if (p.c_bf16 && (p.splitk > 1 || p.R || (p.planes > 0 && p.Wp && p.mode != GEMM_DEFORM_NHWC && p.mode != GEMM_GATHER_NCHW))) return hipErrorInvalidValue;
+    if (p.h2 && !(p.planes == 2 && p.Wp && (p.mode == GEMM_DENSE || p.mode == GEMM_CONV_NHWC))) p.h2 = 0;     // (the fp32-MFMA kernel reads W itself: nothing is scaled)
+    if (p.h2 && !(p.a_scale > 0.f && p.out_scale > 0.f)) return hipErrorInvalidValue;
     if (p.a_planes || p.c_planes) {         // P2 layouts: 2-plane split mode, dense, on the warp-specialised kernel only
         const bool ws_cfg = pl.cfg == 6 || pl.cfg == 0 || pl.cfg == 3 || pl.cfg == 4 || pl.cfg == 5;
         if (!(p.planes == 2 || p.planes == 3) || !p.Wp || p.mode != GEMM_DENSE || !ws_cfg) return hipErrorInvalidValue;

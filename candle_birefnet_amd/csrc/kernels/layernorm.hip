@@ -69,7 +69,8 @@ __global__ void __launch_bounds__(LN_WAVES * 64) layernorm_kernel(const LayerNor
             const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + c4 * 4);
             const f32x4 bt = *reinterpret_cast<const f32x4*>(p.beta + c4 * 4);
             const f32x4 o = (v[i] - mean) * rstd * gm + bt;
-            if (p.y_planes) store_planes_n(p.y_planes, p.y + row * p.ldy, p.y_coff + c4 * 4, o);   // consumer = a split-bf16 GEMM (P layout)
+            if (p.y_planes && p.y_h2 > 0.f) store_planes_h(p.y + row * p.ldy, p.y_coff + c4 * 4, o, p.y_h2);   // consumer = an fp16-pair GEMM (mode f32_half2)
+            else if (p.y_planes) store_planes_n(p.y_planes, p.y + row * p.ldy, p.y_coff + c4 * 4, o);   // consumer = a split-bf16 GEMM (P layout)
             else if (p.y_bf16) {                 // compute mode BRN_BF16: the consumer GEMM reads bf16 (ldy / y_coff in bf16 elements)
                 bf16x4 h;
 #pragma unroll
@@ -86,6 +87,7 @@ hipError_t launch_layernorm(const LayerNormParams& p, hipStream_t s) {
     if (p.mode == 1 && (p.C != 4 * p.Cin || p.Cin % 4)) return hipErrorInvalidValue;
     if (p.y_bf16 && (p.y_planes || p.ldy % 4 || p.y_coff % 4)) return hipErrorInvalidValue;
     if (p.y_planes && (!(p.y_planes == 2 || p.y_planes == 3) || p.C % 32 || p.ldy % 16 || p.y_coff % 32)) return hipErrorInvalidValue;
+    if (p.y_h2 > 0.f && p.y_planes != 2) return hipErrorInvalidValue;
     long blocks = (p.rows + LN_WAVES - 1) / LN_WAVES;
     if (blocks > 2048) blocks = 2048;            // 8 workgroups per CU, grid-stride over rows
     dim3 grid((unsigned)blocks), block(LN_WAVES * 64);

@@ -224,6 +224,10 @@ __global__ void __launch_bounds__(NWV * 64) window_attention_f32_kernel(const Wi
                 float* orow = p.out + (long)qsrc * (C + C / 2);
                 store_planes<3>(orow, head * HD + g * 4, o0 * inv);
                 store_planes<3>(orow, head * HD + 16 + g * 4, o1 * inv);
+            } else if (p.out_planes == 2) { // mode f32_half2: the proj GEMM reads the two fp16 planes (rows as long as fp32 rows)
+                float* orow = p.out + (long)qsrc * C;
+                store_planes_h(orow, head * HD + g * 4, o0 * inv, p.out_h2);
+                store_planes_h(orow, head * HD + 16 + g * 4, o1 * inv, p.out_h2);
             } else if constexpr (IOB) {
                 typedef __bf16 bf16x4_st __attribute__((ext_vector_type(4)));
                 __bf16* op = reinterpret_cast<__bf16*>(p.out) + (long)qsrc * C + head * HD + g * 4;
@@ -714,7 +718,9 @@ hipError_t launch_window_attention2(const WindowAttnParams& p, const WindowAttnP
         if (check_attention(*p2) != hipSuccess || p2->C != p.C || p2->heads != p.heads || p2->planes != p.planes || p2->out_planes != p.out_planes || p2->io_bf16 != p.io_bf16) return hipErrorInvalidValue;
         n1 = p2->B * (p2->Hp / ws) * (p2->Wp / ws);
     }
-    if (p.out_planes && !((p.out_planes == 2 && p.planes == 2) || (p.out_planes == 3 && p.planes == 0))) return hipErrorInvalidValue;
+    if (p.out_planes && !((p.out_planes == 2 && p.planes == 2 && !(p.out_h2 > 0.f)) || (p.out_planes == 3 && p.planes == 0) || (p.out_planes == 2 && p.planes == 0 && p.out_h2 > 0.f && !p.io_bf16)))
+        return hipErrorInvalidValue;
+    if (p2 && p2->out_h2 != p.out_h2) return hipErrorInvalidValue;
     const WindowAttnParams& q = p2 ? *p2 : p;
     dim3 grid(n0 + n1, p.heads), block(ATT_THREADS);
     if (p.io_bf16 && ws == 7) {

@@ -49,6 +49,11 @@ typedef enum { BRN_MEM_HOST = 0, BRN_MEM_DEVICE = 1 } brn_mem;
  *   BRN_F32_SPLIT3     fp32 operands split error-free into 3 bf16 planes, 6 bf16 MFMAs per product, fp32 accumulate:
  *                      fp32-class accuracy (dropped terms < 2^-24 of a product) at 2.67x the fp32-MFMA rate
  *   BRN_F32_SPLIT2     2 planes, 3 MFMAs: ~2^-16 relative per product
+ *   BRN_F32_HALF2      fp32 operands as TWO fp16 planes of the operand scaled by a power of two (weights: per tensor, so that the largest
+ *                      lands in (2^13, 2^14]; activations: by 8), 3 fp16 MFMAs per product (hh, hl, lh), fp32 accumulate, the
+ *                      accumulator un-scaled exactly: ~2^-22 relative per product — fp32-class accuracy at twice BRN_F32_SPLIT3's
+ *                      matrix rate.  Range: a GEMM input activation of magnitude >= 8190 overflows fp16 and the logits come back
+ *                      NaN (never silently wrong); BRN_F32_SPLIT3 has fp32's full range.
  *   BRN_BF16_OPERANDS  operands rounded to bf16, fp32 accumulate, fp32 storage: superseded by BRN_BF16; the value is reserved, the
  *                      product library answers BRN_ERR_INVALID_ARG (only libbirefnet_hip_diag.so, `make diag`, still builds it)
  *   BRN_BF16           the bf16 throughput mode of BASELINE configs[2..4]: activations AND weights live in HBM as bf16,
@@ -57,7 +62,7 @@ typedef enum { BRN_MEM_HOST = 0, BRN_MEM_DEVICE = 1 } brn_mem;
  *   BRN_BF16_DEC_SPLIT2  mixed: the Swin backbone (79 % of the FLOPs) as BRN_BF16, everything after it — multi-scale / context fusion,
  *                      squeeze module, decoder — as BRN_F32_SPLIT2 on fp32 maps.  The decoder's ~20 chained bf16 roundings are most of mode
  *                      BRN_BF16's error; this mode pays for removing them where they are cheapest. */
-typedef enum { BRN_F32 = 0, BRN_F32_SPLIT3 = 1, BRN_F32_SPLIT2 = 2, BRN_BF16_OPERANDS = 3, BRN_BF16 = 4, BRN_BF16_DEC_SPLIT2 = 5 } brn_dtype;
+typedef enum { BRN_F32 = 0, BRN_F32_SPLIT3 = 1, BRN_F32_SPLIT2 = 2, BRN_BF16_OPERANDS = 3, BRN_BF16 = 4, BRN_BF16_DEC_SPLIT2 = 5, BRN_F32_HALF2 = 6 } brn_dtype;
 
 /* D1 of SURVEY.md §8: what DeformConvASPP::forward computes.
  * REFERENCE_CPU = aspp.rs:183-185 (offset/modulator discarded, regular_conv(x)) — the graded parity target.

@@ -28,7 +28,7 @@ def test_hip_kats(gpu, name):
 
 
 # every compute mode that claims fp32 parity must pass the north-star gate (1e-3 abs | 1e-2 rel) with room to spare
-PARITY_MODES = ["f32", "f32_split3", "f32_split2"]
+PARITY_MODES = ["f32", "f32_split3", "f32_split2", "f32_half2"]
 
 
 @pytest.mark.parametrize("mode", PARITY_MODES)

@@ -172,7 +172,7 @@ def test_deform_conv2d(gpu, k, stride, pad, O, H, mode):
     _close(y, ref.numpy(), tol=1e-4 if mode == "deformable" else 3e-5)
 
 
-@pytest.mark.parametrize("mode,tol", [("f32_split3", 3e-5), ("f32_split2", 1e-4)])
+@pytest.mark.parametrize("mode,tol", [("f32_split3", 3e-5), ("f32_split2", 1e-4), ("f32_half2", 3e-5)])
 @pytest.mark.parametrize("M,K,N", [(300, 192, 576), (129, 768, 200), (5000, 384, 1536), (7, 96, 130), (1024, 3072, 768), (64, 51840, 64)])
 def test_linear_split_modes(gpu, mode, tol, M, K, N):
     """the split-bf16 contraction kernels (all tile configs incl. the warp-specialised one and split-K) against fp64"""
@@ -187,7 +187,7 @@ def test_linear_split_modes(gpu, mode, tol, M, K, N):
     _close(y, ref.numpy(), tol=tol)
 
 
-@pytest.mark.parametrize("mode,tol", [("f32_split3", 3e-5), ("f32_split2", 1e-4)])
+@pytest.mark.parametrize("mode,tol", [("f32_split3", 3e-5), ("f32_split2", 1e-4), ("f32_half2", 3e-5)])
 @pytest.mark.parametrize("B,C,H,W,O,k,p", [(2, 64, 16, 16, 256, 3, 1), (1, 64, 20, 12, 256, 7, 3), (1, 96, 33, 31, 64, 3, 1), (1, 480, 64, 64, 64, 3, 1)])
 def test_conv2d_split_modes(gpu, mode, tol, B, C, H, W, O, k, p):
     from candle_birefnet_amd import ops
@@ -199,6 +199,53 @@ def test_conv2d_split_modes(gpu, mode, tol, B, C, H, W, O, k, p):
         ops.set_compute("f32")
     ref = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=p)
     _close(y, ref.numpy(), tol=tol)
+
+
+@pytest.mark.parametrize("astd", [1e-3, 0.03, 1.0, 300.0])
+@pytest.mark.parametrize("M,K,N", [(512, 768, 384), (256, 3072, 256), (200, 96, 64)])
+def test_half2_is_fp32_class_at_every_magnitude(gpu, astd, M, K, N):
+    """Mode f32_half2 (two fp16 planes of the power-of-two-scaled operands, 3 MFMAs per product): the error of a Linear against fp64, relative
+    to the largest output, is that of an fp32 GEMM (a few 1e-7: accumulation noise) for activations of magnitude 0.03 ... 300 and weights
+    of the usual 0.02 scale with one large outlier (the per-tensor weight scale is chosen by the largest weight) — never worse than twice
+    mode f32_split3's on the same data plus 2e-7.  Below |8 x| = 2^-3 the low plane is a subnormal fp16 (absolute step 2^-24 / 8 per
+    element): activations of magnitude 1e-3 measure 1.8e-6, twice f32_split3 and a quarter of f32_split2 — bounded at 4e-6.  This is also
+    where flushed fp16 subnormals in the matrix instruction would show: they would cost 1e-4 here (the MFMA does not flush them)."""
+    from candle_birefnet_amd import ops
+    x, w, b = rnd(M, K, seed=21, std=astd), rnd(N, K, seed=22, std=0.02), rnd(N, seed=23, std=0.1 * astd)
+    w[3, 5] = 0.9
+    ref = (torch.from_numpy(x).double() @ torch.from_numpy(w).double().T + torch.from_numpy(b).double()).numpy()
+    err = {}
+    for mode in ("f32_split3", "f32_half2", "f32_split2"):
+        ops.set_compute(mode)
+        try:
+            y = ops.linear(x, w, b)
+        finally:
+            ops.set_compute("f32")
+        err[mode] = float(np.abs(y.astype(np.float64) - ref).max() / np.abs(ref).max())
+    print(f"|A| ~ {astd:g}, K {K}: relative-to-max error  f32_split3 {err['f32_split3']:.2e}  f32_half2 {err['f32_half2']:.2e}  f32_split2 {err['f32_split2']:.2e}")
+    if astd >= 0.03:
+        assert err["f32_half2"] <= 2.0 * err["f32_split3"] + 2e-7, err
+        assert err["f32_half2"] < 1.5e-6, err
+    else:
+        assert err["f32_half2"] < 4e-6 and err["f32_half2"] < 0.5 * err["f32_split2"], err
+
+
+def test_half2_out_of_range_is_loud(gpu):
+    """an activation beyond the fp16 range of mode f32_half2 (|8 x| >= 65520) gives a non-finite output row, never a wrong finite one; the
+    other rows are untouched"""
+    from candle_birefnet_amd import ops
+    x, w, b = rnd(64, 96, seed=31), rnd(32, 96, seed=32, std=0.1), rnd(32, seed=33)
+    ops.set_compute("f32_half2")
+    try:
+        y0 = ops.linear(x, w, b)
+        x2 = x.copy()
+        x2[7, 11] = 9000.0
+        y1 = ops.linear(x2, w, b)
+    finally:
+        ops.set_compute("f32")
+    assert np.isfinite(y0).all()
+    assert not np.isfinite(y1[7]).any()
+    np.testing.assert_array_equal(np.delete(y1, 7, axis=0), np.delete(y0, 7, axis=0))
 
 
 @pytest.mark.parametrize("mode,tol", [("f32_split2", 1e-4)])
@@ -219,7 +266,7 @@ def test_window_attention_split_modes(gpu, mode, tol, B, H, W, heads, shift):
     _close(y, ref.numpy(), tol=tol)
 
 
-@pytest.mark.parametrize("mode", ["f32_split2", "f32_split3"])
+@pytest.mark.parametrize("mode", ["f32_split2", "f32_split3", "f32_half2"])
 def test_split_conv_exact_and_repeatable(gpu, mode):
     """Small-integer data is exact in every bf16 plane, so the split conv must reproduce the integer result bit for bit,
     every time.  This is the reproducer of a rare wrong-rows fault (packed-fp32 instructions in the staging waves while

@@ -82,7 +82,7 @@ def test_window_attention_window7(gpu, H, W, shift):
 
 
 @pytest.mark.parametrize("name,depths,B,H,W", [("swin_t", [2, 2, 2, 2], 1, 250, 203), ("swin_s", [2, 2, 4, 2], 2, 224, 224), ("swin_b", [2, 2, 2, 2], 1, 131, 90)])
-@pytest.mark.parametrize("compute", ["f32_split3", "f32_split2", "bf16"])
+@pytest.mark.parametrize("compute", ["f32_split3", "f32_split2", "f32_half2", "bf16"])
 def test_swin_configs_in_every_compute_mode(gpu, name, depths, B, H, W, compute):
     """VERDICT r3 missing #3: the stand-alone SwinTransformer in the split and bf16 modes, window 7 included (Swin-T / S: the fp32-MFMA
     attention kernel on the mode's matrices — bf16 in / out in mode bf16 — between the mode's own GEMMs).  Against the CPU oracle: the
