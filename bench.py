@@ -6,7 +6,7 @@
 A "step" = one pass of the hot path over one batch of synthetic images already resident in HBM.  `--config` names a
 BASELINE.json configuration (default c2 = configs[1], the one `metric` is quoted on):
 
-  c2  Swin-L 1024x1024, batch 1,  fp32 (f32_split3: fp32-equivalent arithmetic)   single-image latency, parity-graded
+  c2  Swin-L 1024x1024, batch 1,  fp32 (f32_half2: fp32-equivalent arithmetic)    single-image latency, parity-graded
   c3  Swin-L 1024x1024, batch 8,  bf16 (bf16 storage + bf16 MFMA, fp32 accumulate) MFMA-saturating throughput
   c4  as c3 per GPU (8 images per GPU, weak scaling); --strong: global batch 64 split over the ranks
   c5  Swin-L 2048x2048, batch 4,  bf16
@@ -56,7 +56,7 @@ PROFILE_ROUND = ("r04", "r03", "r02")  # committed rocprofv3 evidence, newest fi
 OTHER_STEPS, OTHER_WARMUP = 20, 5      # timed steps / warm-up of each `other_configs` block (0.6 - 1.2 s regions: barrier skew at N > 1 stays < 1 %)
 # BASELINE.json configs[1..4]: (images per GPU, side, compute mode, label)
 CONFIGS = {
-    "c2": (1, 1024, "f32_split3", "BASELINE configs[1]: Swin-L 1024x1024 batch=1 fp32 on 1xMI355X (single-image latency)"),
+    "c2": (1, 1024, "f32_half2", "BASELINE configs[1]: Swin-L 1024x1024 batch=1 fp32 on 1xMI355X (single-image latency)"),
     "c3": (8, 1024, "bf16", "BASELINE configs[2]: Swin-L 1024x1024 batch=8 bf16 on 1xMI355X (MFMA-saturating throughput)"),
     "c4": (8, 1024, "bf16", "BASELINE configs[3]: Swin-L 1024x1024 batch=64 bf16 sharded across 8xMI355X (8 images per GPU)"),
     "c5": (4, 2048, "bf16", "BASELINE configs[4]: Swin-L 2048x2048 batch=4 bf16 on 1xMI355X (high-res)"),
@@ -109,7 +109,7 @@ def parse_args(argv=None):
     ap.add_argument("--compute", default="", choices=[""] + list(MODES),
                     help="arithmetic of the contraction kernels (include/birefnet_hip.h brn_dtype; overrides --config)")
     ap.add_argument("--strong", action="store_true", help="strong scaling: the config's 8-GPU global batch (images/GPU x 8) is split over the ranks")
-    ap.add_argument("--also", default=None, help="comma list of other compute modes to time briefly on rank 0 at N=1 ('' = none; default: f32_half2,f32_split2,f32 for c2)")
+    ap.add_argument("--also", default=None, help="comma list of other compute modes to time briefly on rank 0 at N=1 ('' = none; default: f32_split3,f32_split2,f32 for c2)")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra steps with per-launch HIP events for the roofline block")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off", "on"])
     ap.add_argument("--other-configs", default="auto", choices=["auto", "off", "on"],
@@ -309,7 +309,7 @@ def main(argv=None):
         B, scaling = gb // world, "strong"
     custom = (B, S, compute) != (cB, cS, cmode) and not args.strong
     default_line = args.config == "c2" and not custom and not args.strong and args.deform_mode == "reference_cpu"
-    also = args.also if args.also is not None else ("f32_half2,f32_split2,f32" if (args.config == "c2" and not custom) else "")
+    also = args.also if args.also is not None else ("f32_split3,f32_split2,f32" if (args.config == "c2" and not custom) else "")
     others_on = args.other_configs == "on" or (args.other_configs == "auto" and default_line)
 
     import numpy as np

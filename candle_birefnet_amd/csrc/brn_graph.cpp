@@ -85,6 +85,7 @@ struct ArenaHold {
     ~ArenaHold() { --a.hold; }
 };
 
+static bool att_h2_on() { static const bool on = !(getenv("BRN_H2_ATT") && atoi(getenv("BRN_H2_ATT")) == 0); return on; }
 // ---- GEMM-shaped pieces -------------------------------------------------------------------------------------------------
 static void fill_epilogue(GemmParams& p, const GemmW& w) {
     p.bias = w.bias; p.scale = w.scale; p.shift = w.shift; p.act = w.act;
@@ -377,7 +378,9 @@ static bool swin_attention_multi(Ctx& c, const SwinBlockW& blk, const float* xn,
             p.Hp = roundup(hs[k], window); p.Wp = roundup(wsz[k], window);   // swin.rs:359-360
             p.ws = window;
             p.shift = shift; p.scale = 1.0f / sqrtf(32.0f);          // head_dim^-0.5 (swin.rs:134)
-            p.planes = (!c.bf16 && !blk.qkv.half && window == 12 && (blk.qkv.planes == 2 || blk.qkv.planes == 1)) ? blk.qkv.planes : 0;   // (f32_half2: the fp32-MFMA kernel, like f32_split3)
+            p.planes = (!c.bf16 && window == 12 && (blk.qkv.planes == 2 || blk.qkv.planes == 1)) ? blk.qkv.planes : 0;
+            p.h2 = (p.planes == 2 && blk.qkv.half && att_h2_on()) ? 1 : 0;
+            if (blk.qkv.half && !p.h2) p.planes = 0;        // BRN_H2_ATT=0: the fp32-MFMA kernel, like f32_split3
             p.out_planes = p2;
             p.out_h2 = (p2 == 2 && blk.qkv.half) ? c.h2_scale : 0.f;
             nwin += (double)B * (p.Hp / window) * (p.Wp / window) * blk.heads;

@@ -129,7 +129,8 @@ struct WindowAttnParams {
     float scale;          // head_dim^-0.5
     int planes;           // 0: fp32 MFMA kernel (modes f32, f32_split3); 2 / 1: bf16-split kernel (f32_split2 / bf16_operands)
     int out_planes;       // 2: write `out` in the P2 layout (kernels/split_planes.h) for the proj GEMM; 0: fp32
-    float out_h2;         // > 0 (with out_planes == 2, planes == 0): fp16 planes of out_h2 * out (mode f32_half2, written by the fp32-MFMA kernel)
+    int h2;               // 1 (with planes == 2): the split kernel on fp16 planes (mode f32_half2)
+    float out_h2;         // > 0 (with out_planes == 2, planes == 0 or h2): fp16 planes of out_h2 * out (mode f32_half2, written by the fp32-MFMA kernel)
     int ws;               // window side: 12 (0 = 12) or 7 (Swin-T / S: fp32 kernel only)
     int io_bf16;          // 1: qkv and out are bf16 matrices (compute mode BRN_BF16; qkv_bias / rel_table stay fp32)
 };

@@ -265,8 +265,13 @@ constexpr int VT_LD = 148;
 
 __device__ __forceinline__ int kswz(int key) { return (0x78 >> (2 * ((key >> 2) & 3))) & 3; }
 
-template <int NP>
+// H (mode f32_half2): the two planes are fp16 planes of the scaled operands (kernels/split_planes.h, split_pair_h) — q (with its head_dim^-0.5), k
+// and v scaled by 8, the un-normalised probabilities (in (0, 1]) by 2048 — on v_mfma_f32_16x16x32_f16; the scores and the output are
+// un-scaled exactly.  ~2^-22 relative per product instead of 2^-16.
+constexpr float ATT_H_QKV = 8.0f, ATT_H_P = 2048.0f;
+template <int NP, bool H = false>
 __global__ void __launch_bounds__(ATT_THREADS) window_attention_split_kernel(const WindowAttnParams pa, const WindowAttnParams pb, const int nblk0) {
+    static_assert(!H || NP == 2, "fp16 planes come in pairs");
     const bool second = (int)blockIdx.x >= nblk0;
     const WindowAttnParams& p = second ? pb : pa;
     __shared__ __attribute__((aligned(16))) __bf16 Kp[NP * NTOK * HD];
@@ -308,6 +313,24 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_split_kernel(con
             kv[u] = *reinterpret_cast<const f32x4*>(kp);
             vv[u] = *reinterpret_cast<const f32x4*>(kp + C);
         }
+        if constexpr (H) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int t = tp * 2 + u;
+                bf16x4 sp[2];
+                split4h<false>(kv[u], 0xffffffffu, ATT_H_QKV, sp);
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    *reinterpret_cast<bf16x4*>(Kp + (pl * NTOK + t) * HD + (((c4 >> 3) ^ kswz(t)) << 3) + (c4 & 4)) = sp[pl];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned hi, lo;
+                split_pair_h(vv[0][e], vv[1][e], ATT_H_QKV, hi, lo);                          // keys (2tp, 2tp+1) of row d = c4+e
+                *reinterpret_cast<unsigned*>(Vt + (c4 + e) * VT_LD + tp * 2) = hi;
+                *reinterpret_cast<unsigned*>(Vt + (HD + c4 + e) * VT_LD + tp * 2) = lo;
+            }
+        } else {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int t = tp * 2 + u;
@@ -335,6 +358,7 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_split_kernel(con
                 if (pl + 1 < NP) { r0[e] -= (float)h[0]; r1[e] -= (float)h[1]; }
             }
         }
+        }
     }
     __syncthreads();
 
@@ -353,6 +377,14 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_split_kernel(con
             float r[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { r[e] = q0[e] * p.scale; r[4 + e] = q1[e] * p.scale; }
+            if constexpr (H) {
+                typedef unsigned u32x4_q __attribute__((ext_vector_type(4)));
+                u32x4_q hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { unsigned a, b2; split_pair_h(r[2 * e], r[2 * e + 1], ATT_H_QKV, a, b2); hi[e] = a; lo[e] = b2; }
+                qf[0] = __builtin_bit_cast(bf16x8, hi);
+                qf[1] = __builtin_bit_cast(bf16x8, lo);
+            } else {
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
@@ -361,6 +393,7 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_split_kernel(con
                     qf[pl][e] = h;
                     r[e] -= (float)h;
                 }
+            }
             }
         }
         f32x4 st[9];
@@ -372,11 +405,17 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_split_kernel(con
             for (int pl = 0; pl < NP; ++pl)
                 kf[pl] = *reinterpret_cast<const bf16x8*>(Kp + (pl * NTOK + key) * HD + ((g ^ kswz(key)) << 3));
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (H) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kf[1]), __builtin_bit_cast(f16x8, qf[0]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kf[0]), __builtin_bit_cast(f16x8, qf[1]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kf[0]), __builtin_bit_cast(f16x8, qf[0]), acc, 0, 0, 0);
+            } else {
             if (NP == 2) {
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1], qf[0], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0], qf[1], acc, 0, 0, 0);
             }
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0], qf[0], acc, 0, 0, 0);
+            }
             st[kt] = acc;
             if (kt % 3 == 2) __builtin_amdgcn_sched_barrier(0);
         }
@@ -386,7 +425,7 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_split_kernel(con
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = kt * 16 + g * 4 + r;
-                float sv = st[kt][r] + tab_s[qbase - key - 11 * (key / WS)];
+                float sv = H ? fmaf(st[kt][r], 1.0f / (ATT_H_QKV * ATT_H_QKV), tab_s[qbase - key - 11 * (key / WS)]) : st[kt][r] + tab_s[qbase - key - 11 * (key / WS)];
                 if (p.shift > 0) sv += ((int)rid_s[key] != qrid) ? -100.0f : 0.0f;
                 st[kt][r] = sv;
                 mx = fmaxf(mx, sv);
@@ -415,6 +454,14 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_split_kernel(con
                 float r[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { r[e] = st[2 * t][e]; r[4 + e] = (2 * t + 1 < 9) ? st[(2 * t + 1 < 9) ? 2 * t + 1 : 0][e] : 0.f; }
+                if constexpr (H) {
+                    typedef unsigned u32x4_p __attribute__((ext_vector_type(4)));
+                    u32x4_p hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { unsigned a, b2; split_pair_h(r[2 * e], r[2 * e + 1], ATT_H_P, a, b2); hi[e] = a; lo[e] = b2; }
+                    pf[0] = __builtin_bit_cast(bf16x8, hi);
+                    pf[1] = __builtin_bit_cast(bf16x8, lo);
+                } else {
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
@@ -423,6 +470,7 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_split_kernel(con
                         pf[pl][e] = h;
                         r[e] -= (float)h;
                     }
+                }
                 }
             }
 #pragma unroll
@@ -438,18 +486,28 @@ __global__ void __launch_bounds__(ATT_THREADS) window_attention_split_kernel(con
                     for (int e = 0; e < 4; ++e) { vf[pl][e] = lo[e]; vf[pl][4 + e] = hi[e]; }
                 }
                 f32x4 o = dt == 0 ? o0 : o1;
+                if constexpr (H) {
+                    o = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vf[1]), __builtin_bit_cast(f16x8, pf[0]), o, 0, 0, 0);
+                    o = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vf[0]), __builtin_bit_cast(f16x8, pf[1]), o, 0, 0, 0);
+                    o = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vf[0]), __builtin_bit_cast(f16x8, pf[0]), o, 0, 0, 0);
+                } else {
                 if (NP == 2) {
                     o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[1], pf[0], o, 0, 0, 0);
                     o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[0], pf[1], o, 0, 0, 0);
                 }
                 o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[0], pf[0], o, 0, 0, 0);
+                }
                 if (dt == 0) o0 = o; else o1 = o;
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (qsrc >= 0) {
-            const float inv = 1.0f / sum;
-            if (p.out_planes == 2) {        // the proj GEMM reads the P layout: a head's 32 outputs are one K tile of the row
+            const float inv = (H ? 1.0f / (ATT_H_P * ATT_H_QKV) : 1.0f) / sum;
+            if (H && p.out_planes == 2) {
+                float* orow = p.out + (long)qsrc * C;
+                store_planes_h(orow, head * HD + g * 4, o0 * inv, p.out_h2);
+                store_planes_h(orow, head * HD + 16 + g * 4, o1 * inv, p.out_h2);
+            } else if (p.out_planes == 2) {        // the proj GEMM reads the P layout: a head's 32 outputs are one K tile of the row
                 float* orow = p.out + (long)qsrc * C;
                 store_planes<2>(orow, head * HD + g * 4, o0 * inv);
                 store_planes<2>(orow, head * HD + 16 + g * 4, o1 * inv);
@@ -718,9 +776,10 @@ hipError_t launch_window_attention2(const WindowAttnParams& p, const WindowAttnP
         if (check_attention(*p2) != hipSuccess || p2->C != p.C || p2->heads != p.heads || p2->planes != p.planes || p2->out_planes != p.out_planes || p2->io_bf16 != p.io_bf16) return hipErrorInvalidValue;
         n1 = p2->B * (p2->Hp / ws) * (p2->Wp / ws);
     }
-    if (p.out_planes && !((p.out_planes == 2 && p.planes == 2 && !(p.out_h2 > 0.f)) || (p.out_planes == 3 && p.planes == 0) || (p.out_planes == 2 && p.planes == 0 && p.out_h2 > 0.f && !p.io_bf16)))
+    if (p.out_planes && !((p.out_planes == 2 && p.planes == 2 && (p.out_h2 > 0.f) == (p.h2 != 0)) || (p.out_planes == 3 && p.planes == 0) || (p.out_planes == 2 && p.planes == 0 && p.out_h2 > 0.f && !p.io_bf16)))
         return hipErrorInvalidValue;
-    if (p2 && p2->out_h2 != p.out_h2) return hipErrorInvalidValue;
+    if (p.h2 && (p.planes != 2 || p.io_bf16)) return hipErrorInvalidValue;
+    if (p2 && (p2->out_h2 != p.out_h2 || p2->h2 != p.h2)) return hipErrorInvalidValue;
     const WindowAttnParams& q = p2 ? *p2 : p;
     dim3 grid(n0 + n1, p.heads), block(ATT_THREADS);
     if (p.io_bf16 && ws == 7) {
@@ -735,7 +794,8 @@ hipError_t launch_window_attention2(const WindowAttnParams& p, const WindowAttnP
         static const bool two_heads = !(getenv("BRN_ATT_HPW") && atoi(getenv("BRN_ATT_HPW")) == 1);
         if (two_heads && !(p.heads & 1)) hipLaunchKernelGGL(window_attention_bf16_kernel<2>, dim3(n0 + n1, p.heads / 2), dim3(2 * ATT_THREADS), 0, s, p, q, n0);
         else hipLaunchKernelGGL(window_attention_bf16_kernel<1>, grid, block, 0, s, p, q, n0);
-    } else if (p.planes == 2) hipLaunchKernelGGL(window_attention_split_kernel<2>, grid, block, 0, s, p, q, n0);
+    } else if (p.planes == 2 && p.h2) hipLaunchKernelGGL((window_attention_split_kernel<2, true>), grid, block, 0, s, p, q, n0);
+    else if (p.planes == 2) hipLaunchKernelGGL(window_attention_split_kernel<2>, grid, block, 0, s, p, q, n0);
 #ifdef BRN_DIAG_BUILD
     else if (p.planes == 1) hipLaunchKernelGGL(window_attention_split_kernel<1>, grid, block, 0, s, p, q, n0);
 #else

@@ -248,7 +248,7 @@ def test_half2_out_of_range_is_loud(gpu):
     np.testing.assert_array_equal(np.delete(y1, 7, axis=0), np.delete(y0, 7, axis=0))
 
 
-@pytest.mark.parametrize("mode,tol", [("f32_split2", 1e-4)])
+@pytest.mark.parametrize("mode,tol", [("f32_split2", 1e-4), ("f32_half2", 2e-5)])
 @pytest.mark.parametrize("B,H,W,heads,shift", [(1, 12, 12, 2, 0), (2, 24, 24, 3, 6), (1, 16, 16, 2, 6), (1, 32, 20, 6, 6), (1, 4, 4, 1, 6), (1, 64, 64, 24, 6)])
 def test_window_attention_split_modes(gpu, mode, tol, B, H, W, heads, shift):
     """the bf16-split attention kernel (window_attention_split_kernel) incl. pad tokens, shift mask, odd geometries"""

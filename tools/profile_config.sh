@@ -13,7 +13,7 @@ SUF=${CFG}${DEFORM:+_deformable}_${MODE}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 D=gpurun_out/prof_${SUF}
 rm -rf $D && mkdir -p $D
-B="python3 bench.py --config $CFG --cpu-baseline off --also= --profile-steps 0 --other-configs off --mask-error off ${DEFORM:+--deform-mode deformable}"
+B="python3 bench.py --config $CFG --compute $MODE --cpu-baseline off --also= --profile-steps 0 --other-configs off --mask-error off ${DEFORM:+--deform-mode deformable}"
 export BRN_SPLIT_STREAMS=1 BRN_BRANCH_STREAMS=0   # one stream, no auxiliary branch streams: kernels run alone
 rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -- $B --steps 3 --warmup 1 > $D/stats.log 2>&1
 echo "[profile] stats done"
@@ -23,7 +23,7 @@ echo "[profile] hbm counters done"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE \
     --kernel-trace --output-format csv -d $D/sq -- $B --steps 1 --warmup 0 > $D/sq.log 2>&1
 echo "[profile] sq counters done"
-BRN_DUMP_LAUNCHES=$D/launches.csv python3 bench.py --config $CFG --cpu-baseline off --also= --profile-steps 1 --other-configs off --mask-error off ${DEFORM:+--deform-mode deformable} --steps 5 --warmup 2 > $D/bench_short.json 2> $D/bench_short.err
+BRN_DUMP_LAUNCHES=$D/launches.csv python3 bench.py --config $CFG --compute $MODE --cpu-baseline off --also= --profile-steps 1 --other-configs off --mask-error off ${DEFORM:+--deform-mode deformable} --steps 5 --warmup 2 > $D/bench_short.json 2> $D/bench_short.err
 python3 tools/make_profiles.py --tag $TAG --suffix $SUF --stats $D/stats --fetch $D/fetch --write $D/write --launches $D/launches.csv --forwards 4
 python3 tools/pmc_sq_summary.py $D/sq profiles/${TAG}_pmc_sq_${SUF}.csv
 if [ "$CFG" != "c2" ]; then
