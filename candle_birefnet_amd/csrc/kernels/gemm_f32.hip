@@ -15,6 +15,7 @@
 // sixteen A (or B) values of a tile are 16 consecutive floats of one LDS row = four ds_read_b128 (row stride
 // 36 floats: conflict-free for the b128 lane groups).  Global->LDS goes through registers (one float4 per
 // thread per 32 rows) with the next tile's loads in flight during the current tile's 64-cycle MFMAs.
+#include <cstdlib>
 #include "../brn_kernels.h"
 #include "split_planes.h"
 
@@ -1370,7 +1371,8 @@ GemmPlan plan_gemm(int M, int N, int K, int planes) {
         const double waste = (double)t128 * 128.0 * 128.0 / ((double)M * N);
         if (waste <= 1.35) {          // N = 192 (1.33) still wins on the warp-specialised kernel: 214 vs 183 TF/s-eq at 81920 x 192 x 768
             pl.cfg = 0; pl.splitk = 1; pl.ws_floats = 0;
-            if (t128 < 200) {
+            static const int sk_t128 = getenv("BRN_SK_T128") ? atoi(getenv("BRN_SK_T128")) : 200;
+            if (t128 < sk_t128) {
                 int s = (int)(480 / t128);
                 if (s > nk / 24) s = nk / 24;
                 if (s > 8) s = 8;
