@@ -47,6 +47,8 @@ MODES = {
     "f32_half2": (3, "f32 storage+accumulate; GEMM operands as two fp16 planes of the power-of-two-scaled operand (22-bit mantissa), 3 fp16 MFMAs/product "
                      "(fp32-equivalent inside the fp16 range: |GEMM input| < 8190)", 4),
     "bf16": (1, "bf16 (activations and weights stored bf16 in HBM, bf16 MFMA, f32 accumulate / LayerNorm / softmax statistics)", 2),
+    "f16": (1, "fp16 (activations and weights stored fp16 in HBM, fp16 MFMA at the bf16 rate, f32 accumulate / LayerNorm / softmax statistics): the bf16 mode's "
+               "graph and kernels with 3 more mantissa bits", 2),
     "bf16_dec_split2": (1, "mixed: Swin backbone as bf16 (79 % of the FLOPs), fusion / squeeze / decoder as f32_split2 on f32 maps (3 bf16 MFMAs / product); "
                            "roofline priced against the bf16 peak", 2),
 }
@@ -474,7 +476,10 @@ def main(argv=None):
         # (the last c3 entry: the same workload in the mixed mode — bf16 backbone, f32_split2 fusion / squeeze / decoder — the arithmetic
         # that brings the mask-space error of the reference_cpu configuration under 1e-3; reported beside c3, it does not replace it)
         plan = ([("c3", "reference_cpu", None), ("c3", "deformable", None), ("c5", "reference_cpu", None), ("c5", "deformable", None),
-                 ("c3", "reference_cpu", "bf16_dec_split2")] if world == 1 else
+                 ("c3", "reference_cpu", "bf16_dec_split2"),
+                 # the same configurations with fp16 instead of bf16 as the 16-bit type (compute mode f16): same kernels, bytes and speed,
+                 # 3 more mantissa bits; reported beside the bf16 lines BASELINE names, they do not replace them
+                 ("c3", "reference_cpu", "f16"), ("c3", "deformable", "f16"), ("c5", "reference_cpu", "f16"), ("c5", "deformable", "f16")] if world == 1 else
                 [("c4", "reference_cpu", None), ("c4", "deformable", None)])
         for cname, dm, cmode_over in plan:
             oB, oS, omode, olabel = CONFIGS[cname]

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("BRN_LIB_PATH") or os.path.join(_HERE, "libbirefnet_hi
 
 BRN_OK = 0
 BRN_MEM_HOST, BRN_MEM_DEVICE = 0, 1
-BRN_F32, BRN_F32_SPLIT3, BRN_F32_SPLIT2, BRN_BF16_OPERANDS, BRN_BF16, BRN_BF16_DEC_SPLIT2, BRN_F32_HALF2 = 0, 1, 2, 3, 4, 5, 6
+BRN_F32, BRN_F32_SPLIT3, BRN_F32_SPLIT2, BRN_BF16_OPERANDS, BRN_BF16, BRN_BF16_DEC_SPLIT2, BRN_F32_HALF2, BRN_F16 = 0, 1, 2, 3, 4, 5, 6, 7
 BRN_DEFORM_REFERENCE_CPU, BRN_DEFORM_DEFORMABLE = 0, 1
 BRN_ACT_NONE, BRN_ACT_RELU, BRN_ACT_GELU_ERF = 0, 1, 2
 

@@ -42,7 +42,7 @@ class BiRefNet:
     """birefnet.rs:380-385.  `BiRefNet.new(config, vb)` == BiRefNet::new (birefnet.rs:389)."""
 
     COMPUTE = {"f32": _ffi.BRN_F32, "f32_split3": _ffi.BRN_F32_SPLIT3, "f32_split2": _ffi.BRN_F32_SPLIT2, "bf16": _ffi.BRN_BF16,
-               "f32_half2": _ffi.BRN_F32_HALF2, "bf16_dec_split2": _ffi.BRN_BF16_DEC_SPLIT2}   # (BRN_BF16_OPERANDS: diag build only; bf16_dec_split2: whole models only)
+               "f32_half2": _ffi.BRN_F32_HALF2, "f16": _ffi.BRN_F16, "bf16_dec_split2": _ffi.BRN_BF16_DEC_SPLIT2}   # (BRN_BF16_OPERANDS: diag build only; bf16_dec_split2: whole models only)
 
     def __init__(self, config: BiRefNetConfig, vb, device: int = 0, max_batch: int = 0, max_size=(0, 0), compute: str = "f32"):
         """vb: a VarBuilder, or the path of a .safetensors checkpoint (read natively by the library: the

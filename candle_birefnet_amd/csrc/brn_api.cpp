@@ -68,7 +68,7 @@ struct Staging {
 };
 
 // run a graph fragment with a private arena: plan (dry), allocate, run
-static void with_arena(hipStream_t s, const std::function<void(Ctx&)>& fn, bool bf16 = false) {
+static void with_arena(hipStream_t s, const std::function<void(Ctx&)>& fn, int bf16 = 0) {   // bf16: 0 fp32 maps, 1 bf16, 2 fp16 (Ctx::bf16)
     Arena a;
     a.dry = true;
     Ctx c{&a, s, true, false, nullptr, nullptr, nullptr};
@@ -335,7 +335,7 @@ static void run_model_locked(Model* m, const float* x, int B, int H, int W, brn_
 using namespace brn;
 
 struct brn_model { Model m; };
-struct brn_swin { brn_config cfg; int device; DeviceOwner own; SwinW w; std::mutex mu; bool bf16 = false; };
+struct brn_swin { brn_config cfg; int device; DeviceOwner own; SwinW w; std::mutex mu; int bf16 = 0; };
 
 extern "C" {
 
@@ -394,15 +394,15 @@ brn_status brn_model_create(const brn_config* cfg, const brn_named_tensor* weigh
 #else
         else if (dt == BRN_BF16_OPERANDS) fail(BRN_ERR_INVALID_ARG, "compute dtype BRN_BF16_OPERANDS is superseded by BRN_BF16 and only built into libbirefnet_hip_diag.so");
 #endif
-        else if (dt == BRN_BF16 || dt == BRN_BF16_DEC_SPLIT2) planes = BUILD_BF16;
+        else if (dt == BRN_BF16 || dt == BRN_BF16_DEC_SPLIT2 || dt == BRN_F16) planes = BUILD_BF16;
         else fail(BRN_ERR_INVALID_ARG, "unsupported compute dtype %d", (int)dt);
-        struct PlanesGuard { PlanesGuard(int p) { set_build_planes(p); } ~PlanesGuard() { set_build_planes(0); } } guard(planes);
+        struct PlanesGuard { PlanesGuard(int p, bool h) { set_build_planes(p); set_build_f16(h); } ~PlanesGuard() { set_build_planes(0); set_build_f16(false); } } guard(planes, dt == BRN_F16);
         *out = nullptr;
         ensure_device(device);
         validate_config(*cfg);
         std::unique_ptr<brn_model> h(new brn_model());
         Model& m = h->m;
-        m.cfg = *cfg; m.device = device; m.bf16 = planes == BUILD_BF16; m.dec_bf16 = dt == BRN_BF16;
+        m.cfg = *cfg; m.device = device; m.bf16 = planes == BUILD_BF16 ? (dt == BRN_F16 ? 2 : 1) : 0; m.dec_bf16 = dt == BRN_BF16 ? 1 : (dt == BRN_F16 ? 2 : 0);
         WeightTable wt(weights, n);
         build_swin_weights(wt, "bb.", *cfg, m.own, m.swin);                               // birefnet.rs:393
         if (dt == BRN_BF16_DEC_SPLIT2) set_build_planes(2);                               // squeeze + decoder weights as two bf16 planes (mode f32_split2)
@@ -426,16 +426,16 @@ brn_status brn_decoder_create(const brn_config* cfg, const brn_named_tensor* wei
         else if (dt == BRN_F32_SPLIT3) planes = 3;
         else if (dt == BRN_F32_SPLIT2) planes = 2;
         else if (dt == BRN_F32_HALF2) planes = BUILD_HALF2;
-        else if (dt == BRN_BF16) planes = BUILD_BF16;
+        else if (dt == BRN_BF16 || dt == BRN_F16) planes = BUILD_BF16;
         else if (dt == BRN_BF16_DEC_SPLIT2) planes = 2;                                    // (a decoder on its own in the mixed mode = mode f32_split2)
         else fail(BRN_ERR_INVALID_ARG, "unsupported compute dtype %d", (int)dt);
-        struct PlanesGuard { PlanesGuard(int p) { set_build_planes(p); } ~PlanesGuard() { set_build_planes(0); } } guard(planes);
+        struct PlanesGuard { PlanesGuard(int p, bool h) { set_build_planes(p); set_build_f16(h); } ~PlanesGuard() { set_build_planes(0); set_build_f16(false); } } guard(planes, dt == BRN_F16);
         *out = nullptr;
         ensure_device(device);
         validate_config(*cfg);
         std::unique_ptr<brn_model> h(new brn_model());
         Model& m = h->m;
-        m.cfg = *cfg; m.device = device; m.bf16 = dt == BRN_BF16; m.dec_bf16 = m.bf16;
+        m.cfg = *cfg; m.device = device; m.bf16 = dt == BRN_BF16 ? 1 : (dt == BRN_F16 ? 2 : 0); m.dec_bf16 = m.bf16;
         WeightTable wt(weights, n);
         build_decoder_weights(wt, prefix ? prefix : "", *cfg, m.own, m.dec);               // birefnet.rs:170-273
         m.has_decoder = true; m.decoder_only = true;
@@ -526,7 +526,7 @@ static void swin_outputs_nchw(Ctx& c, const SwinW& w, const float* dx, int B, in
 }
 
 static void swin_entry(const SwinW& w, int device, const float* x, int B, int H, int W, brn_mem in_loc, float* const outs[4],
-                       brn_mem out_loc, void* stream, bool bf16 = false) {
+                       brn_mem out_loc, void* stream, int bf16 = 0) {
     if (!x || !outs) fail(BRN_ERR_INVALID_ARG, "null argument");
     if (B < 1 || H < 1 || W < 1) fail(BRN_ERR_INVALID_ARG, "bad input shape");
     BRN_HIP(hipSetDevice(device));
@@ -793,6 +793,8 @@ brn_status brn_infer_images_u8(brn_model* mh, int n, const unsigned char* const*
 
 // ---- op-level entry points (weights are always host pointers; x / y / residual follow `loc`) -------------------------------------
 static thread_local int g_op_planes = 0;
+static thread_local bool g_op_f16 = false;      // with BUILD_BF16: fp16 storage (BRN_F16)
+static inline int op_s16(bool bf) { return bf ? (g_op_f16 ? 2 : 1) : 0; }
 brn_status brn_set_op_compute(int dtype) {
     return guarded([&] {
         if (dtype == BRN_F32) g_op_planes = 0;
@@ -804,11 +806,12 @@ brn_status brn_set_op_compute(int dtype) {
 #else
         else if (dtype == BRN_BF16_OPERANDS) fail(BRN_ERR_INVALID_ARG, "compute dtype BRN_BF16_OPERANDS is superseded by BRN_BF16 and only built into libbirefnet_hip_diag.so");
 #endif
-        else if (dtype == BRN_BF16) g_op_planes = BUILD_BF16;
+        else if (dtype == BRN_BF16 || dtype == BRN_F16) g_op_planes = BUILD_BF16;
         else fail(BRN_ERR_INVALID_ARG, "unsupported compute dtype %d", dtype);
+        g_op_f16 = dtype == BRN_F16;
     });
 }
-struct OpPlanes { OpPlanes() { set_build_planes(g_op_planes); } ~OpPlanes() { set_build_planes(0); } };
+struct OpPlanes { OpPlanes() { set_build_planes(g_op_planes); set_build_f16(g_op_f16); } ~OpPlanes() { set_build_planes(0); set_build_f16(false); } };
 
 // ---- stand-alone SwinTransformer -----------------------------------------------------------------------------------------
 brn_status brn_swin_create(const brn_config* cfg, const brn_named_tensor* weights, size_t n, const char* prefix, int device,
@@ -821,7 +824,7 @@ brn_status brn_swin_create(const brn_config* cfg, const brn_named_tensor* weight
         h->cfg = *cfg; h->device = device;
         WeightTable wt(weights, n);
         OpPlanes op_planes;                    // the arithmetic brn_set_op_compute selected on this thread (default BRN_F32)
-        h->bf16 = g_op_planes == BUILD_BF16;
+        h->bf16 = op_s16(g_op_planes == BUILD_BF16);
         build_swin_weights(wt, prefix ? prefix : "", *cfg, h->own, h->w);
         *out = h.release();
     });
@@ -860,9 +863,9 @@ brn_status brn_linear_forward(const float* x, int M, int K, const float* w, cons
             // written it), the product runs on kernels/gemm_bf16.hip, y (and the residual) stay fp32 at this boundary
             with_arena((hipStream_t)stream, [&](Ctx& c) {
                 float* xb = c.arena->alloc_bytes((size_t)M * K * 2);
-                if (!c.dry) BRN_HIP(launch_f32_to_bf16(dx, (size_t)M * K, xb, c.stream));
+                if (!c.dry) BRN_HIP(launch_f32_to_bf16(dx, (size_t)M * K, xb, c.stream, g_op_f16));
                 run_gemm(c, g, xb, M, K, dy, N, 0, dr, N, 0, nullptr, 0, 0, 0, 1, 1);
-            }, true);
+            }, op_s16(true));
         } else
         with_arena((hipStream_t)stream, [&](Ctx& c) { run_gemm(c, g, dx, M, K, dy, N, 0, dr, N, 0); });
         st.finish();
@@ -894,7 +897,7 @@ brn_status brn_linear_residual_layer_norm_forward(const float* x, int M, int K, 
             if (bf) {                                                   // x rounded to bf16 at the edge, y produced as a bf16 matrix and widened
                 float* xb = c.arena->alloc_bytes((size_t)M * K * 2);
                 yb = c.arena->alloc_bytes((size_t)M * N * 2);
-                if (!c.dry) BRN_HIP(launch_f32_to_bf16(dx, (size_t)M * K, xb, c.stream));
+                if (!c.dry) BRN_HIP(launch_f32_to_bf16(dx, (size_t)M * K, xb, c.stream, g_op_f16));
                 a = xb;
             }
             // the residual stream is updated in place inside the model: here x_out starts as a copy of the residual
@@ -903,8 +906,8 @@ brn_status brn_linear_residual_layer_norm_forward(const float* x, int M, int K, 
                 run_gemm(c, g, a, M, K, dxo, N, 0, dxo, N, 0, nullptr, 0, 0, 0, bf ? 1 : 0, bf ? 1 : 0);
                 run_layernorm(c, ln, dxo, M, N, yb, N, 0, 0, bf ? 1 : 0);
             }
-            if (bf && !c.dry) BRN_HIP(launch_bf16_to_f32(yb, (size_t)M * N, dyo, c.stream));
-        }, bf);
+            if (bf && !c.dry) BRN_HIP(launch_bf16_to_f32(yb, (size_t)M * N, dyo, c.stream, g_op_f16));
+        }, op_s16(bf));
         st.finish();
     });
 }
@@ -959,7 +962,7 @@ brn_status brn_conv2d_forward(const float* x, int B, int C, int H, int W, const 
                 run_conv_nchw(c, g, dx, B, H, W, Y);
             }
             if (!c.dry) BRN_HIP(launch_nhwc_to_nchw(Y.p, B, O, Ho, Wo, Y.ld, 0, dy, c.stream, c.bf16));
-        }, bf);
+        }, op_s16(bf));
         st.finish();
     });
 }
@@ -1009,9 +1012,9 @@ brn_status brn_window_attention_forward(const float* x, int B, int H, int W, int
             // the attention output are bf16 matrices (window_attention_bf16_kernel), y = proj(...) stays fp32 like the residual stream
             with_arena((hipStream_t)stream, [&](Ctx& c) {
                 float* xb = c.arena->alloc_bytes((size_t)B * H * W * C * 2);
-                if (!c.dry) BRN_HIP(launch_f32_to_bf16(dx, (size_t)B * H * W * C, xb, c.stream));
+                if (!c.dry) BRN_HIP(launch_f32_to_bf16(dx, (size_t)B * H * W * C, xb, c.stream, g_op_f16));
                 swin_attention(c, bk, xb, B, H, W, C, shift, dy, nullptr, window_size);
-            }, true);
+            }, op_s16(true));
         } else
         with_arena((hipStream_t)stream, [&](Ctx& c) { swin_attention(c, bk, dx, B, H, W, C, shift, dy, nullptr, window_size); });
         st.finish();
@@ -1067,7 +1070,7 @@ brn_status brn_aspp_deformable_forward(const brn_named_tensor* weights, size_t n
             }
             aspp_forward(c, a, T, U, mode);
             if (!c.dry) BRN_HIP(launch_nhwc_to_nchw(U.p, B, a.oc, H, W, U.ld, 0, dy, c.stream, c.bf16));
-        }, g_op_planes == BUILD_BF16);
+        }, op_s16(g_op_planes == BUILD_BF16));
         st.finish();
     });
 }
@@ -1096,7 +1099,7 @@ brn_status brn_decblk_forward(const brn_named_tensor* weights, size_t n, const c
             }
             decblk_forward(c, blk, X, Y, mode);
             if (!c.dry) BRN_HIP(launch_nhwc_to_nchw(Y.p, B, cout, H, W, Y.ld, 0, dy, c.stream, c.bf16));
-        }, bf);
+        }, op_s16(bf));
         st.finish();
     });
 }
@@ -1124,7 +1127,7 @@ brn_status brn_deform_conv2d_forward(const float* x, int B, int C, int H, int W,
         // the bf16 gather kernel), the weights with zero columns
         const bool bf = g_op_planes == BUILD_BF16 && (O % 8) == 0;
         const int Cp = (C + (bf ? 63 : 31)) / (bf ? 64 : 32) * (bf ? 64 : 32);
-        struct Planes { Planes(int p) { set_build_planes(p); } ~Planes() { set_build_planes(0); } } planes_guard(bf ? BUILD_BF16 : 0);
+        struct Planes { Planes(int p) { set_build_planes(p); set_build_f16(p == BUILD_BF16 && g_op_f16); } ~Planes() { set_build_planes(0); set_build_f16(false); } } planes_guard(bf ? BUILD_BF16 : 0);
         std::vector<float> w3((size_t)3 * kk * C * kk), b3((size_t)3 * kk);
         memcpy(w3.data(), offset_w, (size_t)2 * kk * C * kk * sizeof(float));
         memcpy(w3.data() + (size_t)2 * kk * C * kk, mod_w, (size_t)kk * C * kk * sizeof(float));
@@ -1150,7 +1153,7 @@ brn_status brn_deform_conv2d_forward(const float* x, int B, int C, int H, int W,
             if (!c.dry && !fused_sig) BRN_HIP(launch_mod_sigmoid2(OM.p, (size_t)B * Ho * Wo, ldom, 2 * kk, 3 * kk, c.stream));
             run_conv(c, reg, X, Y, OM.p, ldom, 2 * kk, 0, fused_sig ? 1 : 0);
             if (!c.dry) BRN_HIP(launch_nhwc_to_nchw(Y.p, B, O, Ho, Wo, Y.ld, 0, dy, c.stream, c.bf16));
-        }, bf);
+        }, op_s16(bf));
         st.finish();
     });
 }

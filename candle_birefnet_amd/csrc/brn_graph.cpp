@@ -86,6 +86,8 @@ struct ArenaHold {
 };
 
 static bool att_h2_on() { static const bool on = !(getenv("BRN_H2_ATT") && atoi(getenv("BRN_H2_ATT")) == 0); return on; }
+// compute mode BRN_F16 (c.bf16 == 2): the 16-bit kernels of namespace brn::hf (fp16 storage / MFMA operands)
+#define S16F(C_, FN_) ((C_).bf16 == 2 ? hf::FN_ : FN_)
 // ---- GEMM-shaped pieces -------------------------------------------------------------------------------------------------
 static void fill_epilogue(GemmParams& p, const GemmW& w) {
     p.bias = w.bias; p.scale = w.scale; p.shift = w.shift; p.act = w.act;
@@ -97,7 +99,7 @@ static void fill_epilogue(GemmParams& p, const GemmW& w) {
 // bf16-storage mode: the same GEMM on kernels/gemm_bf16.hip (A bf16; C / R bf16 unless flagged fp32)
 static void run_gemm_bf16(Ctx& c, const GemmW& w, GemmParams& p, int fam) {
     if (!w.wb) fail(BRN_ERR_INVALID_ARG, "bf16 mode: weight without a bf16 copy");
-    const GemmPlan pl = plan_gemm_bf16(p.M, p.N, p.K, p.c_f32 && p.R && p.r_f32, p.act == ACT_GELU_ERF);
+    const GemmPlan pl = S16F(c, plan_gemm_bf16)(p.M, p.N, p.K, p.c_f32 && p.R && p.r_f32, p.act == ACT_GELU_ERF);
     const size_t mk = c.arena->mark();
     float* ws = pl.ws_floats ? c.arena->alloc(pl.ws_floats) : nullptr;
     c.arena->release(mk);
@@ -107,11 +109,11 @@ static void run_gemm_bf16(Ctx& c, const GemmW& w, GemmParams& p, int fam) {
     if (w.wf && w.mode == GEMM_DENSE && (wstat_mask & (p.K == 384 ? 2 : 1))) {   // short K, wide A: the weights stay in registers (gemm_wstat_bf16_kernel)
         GemmParams q = p;
         q.Wp = w.wf;
-        if (gemm_wstat_eligible(q)) {
+        if (S16F(c, gemm_wstat_eligible)(q)) {
             const double flop_ = 2.0 * q.M * (double)q.N * q.K;
             const double bytes_ = 2.0 * ((double)q.M * q.K + (double)q.N * q.K + (double)q.M * q.N);
             Bracket b(c, fam, flop_, bytes_, q.M, q.N, q.K);
-            BRN_LAUNCH(launch_gemm_wstat(q, c.stream));
+            BRN_LAUNCH(S16F(c, launch_gemm_wstat)(q, c.stream));
             return;
         }
     }
@@ -119,7 +121,7 @@ static void run_gemm_bf16(Ctx& c, const GemmW& w, GemmParams& p, int fam) {
     const double a_elems = p.mode == GEMM_DENSE ? (double)p.M * p.K : (double)p.M / ((double)p.Hout * p.Wout) * p.Hin * p.Win * p.Cin;
     const double bytes = 2.0 * (a_elems + (double)p.N * p.K) + (p.c_f32 ? 4.0 : 2.0) * (double)p.M * p.N + (p.R ? (p.r_f32 ? 4.0 : 2.0) * (double)p.M * p.N : 0.0);
     Bracket b(c, fam, flop, bytes, p.M, p.N, p.K);
-    const hipError_t e = launch_gemm_bf16(p, pl, ws, c.stream);
+    const hipError_t e = S16F(c, launch_gemm_bf16)(p, pl, ws, c.stream);
     if (e != hipSuccess)
         fail(BRN_ERR_HIP, "launch_gemm_bf16 (M %d, N %d, K %d, mode %d, Cin %d, %d x %d -> %d x %d, lda %d + %d, ldc %d + %d, tile cfg %d, split-K %d, chunk-major %d): %s",
              p.M, p.N, p.K, p.mode, p.Cin, p.Hin, p.Win, p.Hout, p.Wout, p.lda, p.a_coff, p.ldc, p.c_coff, pl.cfg, pl.splitk, p.k_chunk_major, hipGetErrorString(e));
@@ -224,13 +226,13 @@ void run_conv(Ctx& c, const GemmW& w, const Map& in, const Map& out, const float
     if (deform_fused_sigmoid(c, w) && !c_f32) {
         if (!om) fail(BRN_ERR_INVALID_ARG, "deformable conv without an offset/modulator map");
         GemmParams p = deform_bf16_params(w, in, out, Hout, Wout, om, om_ld, om_mask_off, om_sigmoid);
-        if (deform_bf16_eligible(p)) {
+        if (S16F(c, deform_bf16_eligible)(p)) {
             if (c.dry) return;
             const double flop = 2.0 * M * (double)w.N * w.K;
             // algorithmic bytes: the sampled map once, the offset / modulator map, the weights, the result
             const double bytes = 2.0 * ((double)in.pixels() * w.Cinp + (double)w.N * w.K + (double)M * w.N) + 4.0 * M * 3.0 * w.kh * w.kw;
             Bracket b(c, FAM_GEMM_DEFORM, flop, bytes, M, w.N, w.K);
-            BRN_LAUNCH(launch_deform_bf16(p, c.stream));
+            BRN_LAUNCH(S16F(c, launch_deform_bf16)(p, c.stream));
             return;
         }
         if (om_sigmoid) fail(BRN_ERR_INVALID_ARG, "deformable conv: raw modulator logits passed to a shape the bf16 gather kernel does not cover");
@@ -249,7 +251,7 @@ void run_conv(Ctx& c, const GemmW& w, const Map& in, const Map& out, const float
     p.om = om; p.om_ld = om_ld; p.om_mask_off = om_mask_off;
     fill_epilogue(p, w);
     p.bbias_rows = 1; p.ldc = out.ld; p.c_coff = out.coff;
-    if (c.bf16) { p.a_bf16 = 1; p.c_bf16 = c_f32 ? 0 : 1; }   // deformable gather in bf16 mode: bf16 map in / out on the fp32-MFMA kernel
+    if (c.bf16) { p.a_bf16 = c.bf16; p.c_bf16 = c_f32 ? 0 : c.bf16; }   // deformable gather in bf16 mode: bf16 map in / out on the fp32-MFMA kernel
     if (w.mode == GEMM_DEFORM_NHWC && !om) fail(BRN_ERR_INVALID_ARG, "deformable conv without an offset/modulator map");
     const double flop = 2.0 * M * (double)w.N * w.K;
     const double bytes = 4.0 * ((double)in.pixels() * w.Cinp + (double)w.N * w.K + (double)M * w.N);
@@ -331,23 +333,23 @@ bool linear_residual_ln(Ctx& c, const GemmW& w, const float* A, int M, int lda, 
     // wide stages: the workgroup owns 64 whole rows and W streams through LDS (gemm_rowln_bf16_kernel)
     if (w.wb && (rowln_mask & (w.N == 768 ? 1 : w.N == 384 ? 2 : 0))) {
         p.Wp = w.wb; p.wp_rows = w.wb_rows; p.wp_ld = w.wb_ld;
-        if (gemm_rowln_eligible(p)) {
+        if (S16F(c, gemm_rowln_eligible)(p)) {
             if (c.dry) return true;
             const double flop = 2.0 * M * (double)w.N * w.K;
             const double bytes = 2.0 * ((double)M * w.K + (double)w.N * w.K) + (4.0 + 4.0 + 2.0) * (double)M * w.N;
             Bracket b(c, FAM_GEMM_DENSE, flop, bytes, M, w.N, w.K);
-            BRN_LAUNCH(launch_gemm_rowln(p, ln.g, ln.b, 1e-5f, y, ldy, c.stream));
+            BRN_LAUNCH(S16F(c, launch_gemm_rowln)(p, ln.g, ln.b, 1e-5f, y, ldy, c.stream));
             return true;
         }
     }
     if (off || !w.wf) return false;
     p.Wp = w.wf; p.wp_rows = 0; p.wp_ld = 0;
-    if (!gemm_wstat_ln_eligible(p)) return false;
+    if (!S16F(c, gemm_wstat_ln_eligible)(p)) return false;
     if (c.dry) return true;
     const double flop = 2.0 * M * (double)w.N * w.K;
     const double bytes = 2.0 * ((double)M * w.K + (double)w.N * w.K) + (4.0 + 4.0 + 2.0) * (double)M * w.N;
     Bracket b(c, FAM_GEMM_DENSE, flop, bytes, M, w.N, w.K);
-    BRN_LAUNCH(launch_gemm_wstat_ln(p, ln.g, ln.b, 1e-5f, y, ldy, c.stream));
+    BRN_LAUNCH(S16F(c, launch_gemm_wstat_ln)(p, ln.g, ln.b, 1e-5f, y, ldy, c.stream));
     return true;
 }
 
@@ -435,7 +437,7 @@ void swin_forward_multi(Ctx& c, const SwinW& w, const SwinIn* ins, int nin, int 
                 const LNW* n1 = xn0 ? &w.stages[0].blocks[0].norm1 : nullptr;
                 BRN_LAUNCH(launch_patch_embed_ln(ins[k].img, B, ins[k].H, ins[k].W, w.patch_proj.w, w.patch_proj.K, w.patch_proj.bias, w.patch_norm.g,
                                                  w.patch_norm.b, 1e-5f, x + off * E, E, c.stream, n1 ? n1->g : nullptr, n1 ? n1->b : nullptr,
-                                                 xn0 ? c.at(xn0, off * E) : nullptr, E));
+                                                 xn0 ? c.at(xn0, off * E) : nullptr, E, c.bf16 == 2));
             }
             off += rows(k, 0);
         }
@@ -714,7 +716,7 @@ void decoder_forward(Ctx& c, const Model& m, const float* img, int B, int H, int
     float* tl = c.arena->alloc((size_t)B * H * W);
     if (!c.dry) {
         Bracket b(c, FAM_ELEMENTWISE, 2.0 * B * H * (double)W * 75, 4.0 * B * H * (double)W * 5);
-        BRN_LAUNCH(launch_pixel_dot(p1.p, B * h1 * w1, 192, p1.ld, p1.coff, d.out_w, 0.f, q, c.stream, c.bf16 && !p1_f32));
+        BRN_LAUNCH(launch_pixel_dot(p1.p, B * h1 * w1, 192, p1.ld, p1.coff, d.out_w, 0.f, q, c.stream, p1_f32 ? 0 : c.bf16));
         BRN_LAUNCH(launch_head_stencil5x5(img, B, H, W, d.head_k, d.head_b, tl, c.stream));
         BRN_LAUNCH(launch_final_head(q, B, h1, w1, tl, d.out_b, H, W, apply_sigmoid, out, c.stream));
     }
@@ -729,7 +731,7 @@ void model_forward(Model& m, Ctx& c, const float* img, int B, int H, int W, floa
     auto stamp = [&](int i) { if (prof) BRN_HIP(hipEventRecord(m.stage_ev[i], c.stream)); };
     // Ctx::bf16 says what the maps being allocated / the kernels being launched hold: the backbone's setting (m.bf16) inside
     // swin_forward_multi, the decoder side's (m.dec_bf16) everywhere else — the two differ only in the mixed mode BRN_BF16_DEC_SPLIT2
-    struct Bf16Scope { Ctx& c; bool old; Bf16Scope(Ctx& c_, bool v) : c(c_), old(c_.bf16) { c.bf16 = v; } ~Bf16Scope() { c.bf16 = old; } };
+    struct Bf16Scope { Ctx& c; int old; Bf16Scope(Ctx& c_, int v) : c(c_), old(c_.bf16) { c.bf16 = v; } ~Bf16Scope() { c.bf16 = old; } };
     Bf16Scope dec_scope(c, m.dec_bf16);
     const size_t mk = c.arena->mark();
     const int h1 = H / 4, w1 = W / 4, h2 = H / 8, w2 = W / 8, h3 = H / 16, w3 = W / 16, h4 = H / 32, w4 = W / 32;

@@ -71,7 +71,7 @@ struct Ctx {
     std::vector<LaunchRecord>* records;
     std::vector<hipEvent_t>* event_pool; size_t* event_next;
     // compute mode BRN_BF16: activation maps are bf16 in HBM (esz = 2); pointers stay typed float* and are opaque to the host
-    bool bf16 = false;
+    int bf16 = 0;                   // 0: fp32 maps; 1: bf16 (BRN_BF16); 2: fp16 (BRN_F16: the same graph, kernels of namespace brn::hf / the fp16 flavours)
     float h2_scale = 0.f;   // > 0 inside a Swin stage of mode f32_half2: P2-layout producers write fp16 planes of h2_scale * x (kernels/split_planes.h)
     int region = REGION_NONE;       // tag of the launches being recorded (profiling only)
     BranchSet* br = nullptr;        // null: every branch stays on `stream` (profiled forwards, the op-level entry points)
@@ -217,8 +217,8 @@ struct Model {
     bool profiling = false;
     int opt_parts = 0;        // brn_model_set_streams: sub-batch streams of a device-resident batch (0 = BRN_SPLIT_STREAMS / default 2)
     int opt_branches = -2;    // ... and the mask of auxiliary branch streams (-2 = BRN_BRANCH_STREAMS / default; -1 = automatic; 0 = none)
-    bool bf16 = false;        // BRN_BF16 / BRN_BF16_DEC_SPLIT2: the backbone's activations / weights are bf16 in HBM
-    bool dec_bf16 = false;    // the fusion / squeeze / decoder part too (BRN_BF16); false in BRN_BF16_DEC_SPLIT2: fp32 maps, split-bf16 GEMMs
+    int bf16 = 0;             // BRN_BF16 / BRN_BF16_DEC_SPLIT2: the backbone's activations / weights are bf16 in HBM (1); BRN_F16: fp16 (2)
+    int dec_bf16 = 0;        // the fusion / squeeze / decoder part too (BRN_BF16); false in BRN_BF16_DEC_SPLIT2: fp32 maps, split-bf16 GEMMs
     std::vector<LaunchRecord> records;
     std::vector<hipEvent_t> event_pool; size_t event_next = 0;
     hipEvent_t stage_ev[6]; bool stage_ev_ok = false;
@@ -290,6 +290,7 @@ void ensure_device(int ordinal);
 // number of bf16 planes the weight builders attach to every dense / channels-last conv GemmW (0 = fp32 MFMA path only);
 // BUILD_BF16: attach the plain bf16 matrix of the bf16-storage mode instead
 constexpr int BUILD_BF16 = 16;
+void set_build_f16(bool on);      // with BUILD_BF16: the 16-bit copies are fp16 (compute mode BRN_F16)
 constexpr int BUILD_HALF2 = 18;   // two fp16 planes of the scaled matrix (mode f32_half2)
 float half2_act_scale();          // the power of two GEMM activations are scaled by before the fp16 split (BRN_H2_ASCALE, default 8)
 void set_build_planes(int planes);

@@ -79,7 +79,7 @@ hipError_t launch_gemm_wstat(const GemmParams& p, hipStream_t s);
 bool patch_embed_ln_eligible(int Cin, int N, int k, int stride, int H, int W, int ldw, int ldx);
 hipError_t launch_patch_embed_ln(const float* img, int B, int H, int W, const float* wgt, int ldw, const float* bias, const float* gamma,
                                  const float* beta, float eps, float* x, int ldx, hipStream_t s, const float* gamma1 = nullptr,
-                                 const float* beta1 = nullptr, void* xn_bf16 = nullptr, int ldxn = 0);   // (gamma1 / beta1 / xn: also LayerNorm(x) gamma1 + beta1 as a bf16 matrix)
+                                 const float* beta1 = nullptr, void* xn_bf16 = nullptr, int ldxn = 0, int xn_f16 = 0);   // (gamma1 / beta1 / xn: also LayerNorm(x) gamma1 + beta1 as a bf16 matrix)
 bool gemm_wstat_ln_eligible(const GemmParams& p);
 // the same fusion for N = 768 / 384 (any K % 32 == 0): gemm_rowln_bf16_kernel, a workgroup owns 64 whole rows, Wp = the plain [wp_rows][wp_ld] bf16 matrix
 bool gemm_rowln_eligible(const GemmParams& p);
@@ -95,6 +95,21 @@ hipError_t launch_deform_bf16(const GemmParams& p, hipStream_t s);
 bool gemm_planes_eligible(const GemmParams& p);
 GemmPlan plan_gemm_planes(int M, int N, int K, int planes, bool c_planes);
 hipError_t launch_gemm_planes(const GemmParams& p, const GemmPlan& plan, float* ws, hipStream_t s);
+
+// compute mode BRN_F16: the same kernels with fp16 as the 16-bit storage / MFMA operand type (kernels/gemm_bf16.hip and kernels/deform_bf16.hip
+// compiled with -DBRN_S16_F16=1).  Same contracts as the functions of the same name above.
+namespace hf {
+GemmPlan plan_gemm_bf16(int M, int N, int K, bool f32_residual = false, bool gelu = false);
+hipError_t launch_gemm_bf16(const GemmParams& p, const GemmPlan& plan, float* ws, hipStream_t s);
+bool gemm_wstat_eligible(const GemmParams& p);
+hipError_t launch_gemm_wstat(const GemmParams& p, hipStream_t s);
+bool gemm_wstat_ln_eligible(const GemmParams& p);
+hipError_t launch_gemm_wstat_ln(const GemmParams& p, const float* gamma, const float* beta, float eps, void* y_bf16, int ldy, hipStream_t s);
+bool gemm_rowln_eligible(const GemmParams& p);
+hipError_t launch_gemm_rowln(const GemmParams& p, const float* gamma, const float* beta, float eps, void* y_bf16, int ldy, hipStream_t s);
+bool deform_bf16_eligible(const GemmParams& p);
+hipError_t launch_deform_bf16(const GemmParams& p, hipStream_t s);
+}  // namespace hf
 
 #ifdef BRN_DIAG_BUILD
 hipError_t launch_mfma_valu_probe(int blocks, int iters, int mode, float* sink, hipStream_t s);
@@ -164,8 +179,8 @@ hipError_t launch_gdt_gate(float* p, int npix, int C, int ldp, int p_coff, const
 hipError_t launch_pixel_dot(const float* x, int npix, int C, int ldx, int x_coff, const float* w, float bias,
                             float* y, hipStream_t s, int bf16 = 0);
 // contiguous fp32 -> bf16 (round to nearest even)
-hipError_t launch_f32_to_bf16(const float* x, size_t n, float* y_bf16, hipStream_t s);
-hipError_t launch_bf16_to_f32(const float* x_bf16, size_t n, float* y, hipStream_t s);
+hipError_t launch_f32_to_bf16(const float* x, size_t n, float* y_bf16, hipStream_t s, int f16 = 0);   // f16: fp16 instead (compute mode BRN_F16)
+hipError_t launch_bf16_to_f32(const float* x_bf16, size_t n, float* y, hipStream_t s, int f16 = 0);
 // final head (birefnet.rs:372-375 with conv_out1 commuted through the bilinear upsample):
 // out[b][oy][ox] = bilinear(q [B,h,w] -> H,W) + t[b][oy][ox] (+bias); optional sigmoid
 hipError_t launch_final_head(const float* q, int B, int h, int w, const float* t, float bias, int H, int W,

@@ -71,6 +71,8 @@ const brn_named_tensor* WeightTable::get(const std::string& name, std::initializ
 static inline int roundup(int x, int m) { return (x + m - 1) / m * m; }
 
 static thread_local int g_build_planes = 0;
+static thread_local bool g_build_f16 = false;
+void set_build_f16(bool on) { g_build_f16 = on; }
 void set_build_planes(int planes) { g_build_planes = planes; }
 int build_planes() { return g_build_planes; }
 
@@ -120,6 +122,7 @@ float half2_act_scale() {
     }();
     return s;
 }
+static inline uint16_t s16_rne(float x) { return g_build_f16 ? f16_rne(x) : bf16_rne(x); }   // the 16-bit storage type of the build (BRN_BF16 / BRN_F16)
 // error-free split of the packed fp32 matrix [rows][K] into bf16 planes: plane p = RN_bf16(x - sum of the previous planes),
 // stored interleaved per 32-deep K tile: [row][K/32][plane][32] (a (row, K tile) is NP x 64 contiguous bytes)
 static void attach_planes(DeviceOwner& own, GemmW& g, const std::vector<float>& pk, int rows) {
@@ -139,7 +142,7 @@ static void attach_planes(DeviceOwner& own, GemmW& g, const std::vector<float>& 
             for (size_t k = 0; k < K; ++k) {
                 size_t kd = k;
                 if (cm) { const size_t t = k / cinp, ci = k - t * cinp; kd = ((ci >> 6) * kk + t) * 64 + (ci & 63); }
-                wb[r * ld + kd] = bf16_rne(pk[r * K + k]);
+                wb[r * ld + kd] = s16_rne(pk[r * K + k]);
             }
         g.wb_chunk_major = cm ? 1 : 0;
         void* d = nullptr;
@@ -243,7 +246,7 @@ void attach_deform_frags(DeviceOwner& own, GemmW& g, const float* w) {
             for (int ci = 0; ci < g.Cin; ++ci) {
                 const int k = t * g.Cinp + ci;
                 const int kt = k >> 6, s = (k >> 5) & 1, lane = ((k >> 3) & 3) * 16 + (n & 15), e = k & 7;
-                wf[((((size_t)(n >> 4) * nk + kt) * 2 + s) * 64 + lane) * 8 + e] = bf16_rne(w[((size_t)n * g.Cin + ci) * kk + t]);
+                wf[((((size_t)(n >> 4) * nk + kt) * 2 + s) * 64 + lane) * 8 + e] = s16_rne(w[((size_t)n * g.Cin + ci) * kk + t]);
             }
     void* d = nullptr;
     hipError_t e = hipMalloc(&d, wf.size() * 2 + 16);
@@ -260,7 +263,7 @@ void attach_dense_frags(DeviceOwner& own, GemmW& g, const float* w) {
     for (int n = 0; n < g.N; ++n)
         for (int k = 0; k < g.K; ++k) {
             const int lane = ((k >> 3) & 3) * 16 + (n & 15);
-            wf[(((size_t)(n >> 4) * k32 + (k >> 5)) * 64 + lane) * 8 + (k & 7)] = bf16_rne(w[(size_t)n * g.K + k]);
+            wf[(((size_t)(n >> 4) * k32 + (k >> 5)) * 64 + lane) * 8 + (k & 7)] = s16_rne(w[(size_t)n * g.K + k]);
         }
     void* d = nullptr;
     hipError_t e = hipMalloc(&d, wf.size() * 2 + 16);

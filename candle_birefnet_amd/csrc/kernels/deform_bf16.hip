@@ -25,7 +25,41 @@
 #include <cstdlib>
 #include <type_traits>
 
+// Compiled twice like gemm_bf16.hip: -DBRN_S16_F16=1 builds the fp16-storage flavour (compute mode BRN_F16) in namespace brn::hf.
+#ifndef BRN_S16_F16
+#define BRN_S16_F16 0
+#endif
 namespace brn {
+#if BRN_S16_F16
+namespace hf {
+typedef _Float16 s16_t;
+#define BRN_MFMA_16X16X32(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, C, 0, 0, 0)
+#else
+typedef __bf16 s16_t;
+#define BRN_MFMA_16X16X32(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, C, 0, 0, 0)
+#endif
+typedef s16_t s16x8 __attribute__((ext_vector_type(8)));
+#if BRN_S16_F16      // (an unqualified call would also find the brn:: function of the same name through its brn::GemmParams argument)
+#define BRN_S16_SELF(FN) hf::FN
+#else
+#define BRN_S16_SELF(FN) FN
+#endif
+__device__ __forceinline__ float d16_lo_f32(unsigned r) {
+#if BRN_S16_F16
+    typedef _Float16 h2_d __attribute__((ext_vector_type(2)));
+    return (float)__builtin_bit_cast(h2_d, r)[0];
+#else
+    return __builtin_bit_cast(float, r << 16);
+#endif
+}
+__device__ __forceinline__ float d16_hi_f32(unsigned r) {
+#if BRN_S16_F16
+    typedef _Float16 h2_d __attribute__((ext_vector_type(2)));
+    return (float)__builtin_bit_cast(h2_d, r)[1];
+#else
+    return __builtin_bit_cast(float, r & 0xffff0000u);
+#endif
+}
 
 typedef float f32x4_d __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4_d __attribute__((ext_vector_type(4)));
@@ -34,8 +68,8 @@ typedef unsigned u32x2_d __attribute__((ext_vector_type(2)));
 constexpr int DBM = 64, DBN = 256, DBK = 64;
 
 __device__ __forceinline__ unsigned dpack2(float lo, float hi) {
-    typedef __bf16 bf16x2_d __attribute__((ext_vector_type(2)));
-    const bf16x2_d t = {(__bf16)lo, (__bf16)hi};
+    typedef s16_t s16x2_d __attribute__((ext_vector_type(2)));
+    const s16x2_d t = {(s16_t)lo, (s16_t)hi};
     return __builtin_bit_cast(unsigned, t);
 }
 // byte offset of 16-byte chunk c (0..7) of tile row r (128-byte rows) in the swizzled A image
@@ -60,7 +94,7 @@ __global__ void __launch_bounds__(256, 2) gemm_deform_bf16_kernel(const GemmPara
 
     // ---- gather state of this thread's two rows ----
     const int gc = tid & 7, gr = tid >> 3;
-    const __bf16* Ab = reinterpret_cast<const __bf16*>(p.A);
+    const s16_t* Ab = reinterpret_cast<const s16_t*>(p.A);
     const char* a_img[2];        // first byte of (image b, channel a_coff + 8 gc)
     const float* om_row[2];
     int iy0[2], ix0[2];
@@ -124,8 +158,8 @@ __global__ void __launch_bounds__(256, 2) gemm_deform_bf16_kernel(const GemmPara
                 float lo = 0.f, hi = 0.f;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    lo = fmaf(gw[i][c], __builtin_bit_cast(float, gv[i][c][e] << 16), lo);
-                    hi = fmaf(gw[i][c], __builtin_bit_cast(float, gv[i][c][e] & 0xffff0000u), hi);
+                    lo = fmaf(gw[i][c], d16_lo_f32(gv[i][c][e]), lo);
+                    hi = fmaf(gw[i][c], d16_hi_f32(gv[i][c][e]), hi);
                 }
                 o[e] = dpack2(lo, hi);
             }
@@ -155,21 +189,21 @@ __global__ void __launch_bounds__(256, 2) gemm_deform_bf16_kernel(const GemmPara
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const char* abuf = smem + (kt & 1) * (DBM * DBK * 2);
-        bf16x8 wfr[4][2];
+        s16x8 wfr[4][2];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) wfr[j][s] = *reinterpret_cast<const bf16x8*>(wf + j * wf_nb + (long)(kt * 2 + s) * 1024);
+            for (int s = 0; s < 2; ++s) wfr[j][s] = *reinterpret_cast<const s16x8*>(wf + j * wf_nb + (long)(kt * 2 + s) * 1024);
         if (kt + 1 < nk) gather_issue(kt + 1);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 af[4];
+            s16x8 af[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(abuf + a_foff[i][s]);
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const s16x8*>(abuf + a_foff[i][s]);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[j][s], af[i], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) acc[i][j] = BRN_MFMA_16X16X32(wfr[j][s], af[i], acc[i][j]);
         }
         if (kt + 1 < nk) gather_finish(smem + ((kt + 1) & 1) * (DBM * DBK * 2));
         __syncthreads();
@@ -203,7 +237,7 @@ __global__ void __launch_bounds__(256, 2) gemm_deform_bf16_kernel(const GemmPara
     }
     __syncthreads();
     {
-        __bf16* Cb = reinterpret_cast<__bf16*>(p.C);
+        s16_t* Cb = reinterpret_cast<s16_t*>(p.C);
 #pragma unroll
         for (int ps = 0; ps < DBM / 8; ++ps) {
             const int row = ps * 8 + (tid >> 5), c = tid & 31;
@@ -247,9 +281,9 @@ __global__ void __launch_bounds__(256, 2) gemm_deform_bf16_v2_kernel(const GemmP
     const int nk = p.K / DBK;
     const int pix_bytes = p.lda * 2;
     const int b0 = min(m0, p.M - 1) / hw;            // first image of the tile: the base of the buffer resource
-    const __bf16* Ab = reinterpret_cast<const __bf16*>(p.A);
+    const s16_t* Ab = reinterpret_cast<const s16_t*>(p.A);
     const __amdgpu_buffer_rsrc_t a_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Ab + (long)b0 * p.Hin * p.Win * p.lda + p.a_coff), 0, (int)0xffffffffu, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<s16_t*>(Ab + (long)b0 * p.Hin * p.Win * p.lda + p.a_coff), 0, (int)0xffffffffu, 0x00020000);
 
     // ---- parameter role: lane = (pixel pi of this wave's 16, tap tq of the current block of 4) ----
     const int pi = lane & 15, tq = lane >> 4;
@@ -338,8 +372,8 @@ __global__ void __launch_bounds__(256, 2) gemm_deform_bf16_v2_kernel(const GemmP
                 float lo = 0.f, hi = 0.f;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    lo = fmaf(gw[0][i][c], __builtin_bit_cast(float, gv[S][i][c][e] << 16), lo);
-                    hi = fmaf(gw[0][i][c], __builtin_bit_cast(float, gv[S][i][c][e] & 0xffff0000u), hi);
+                    lo = fmaf(gw[0][i][c], d16_lo_f32(gv[S][i][c][e]), lo);
+                    hi = fmaf(gw[0][i][c], d16_hi_f32(gv[S][i][c][e]), hi);
                 }
                 o[e] = dpack2(lo, hi);
             }
@@ -359,11 +393,11 @@ __global__ void __launch_bounds__(256, 2) gemm_deform_bf16_v2_kernel(const GemmP
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_d{0.f, 0.f, 0.f, 0.f};
-    bf16x8 wfr[2][4];                                                    // [half step s][n16 block j]
+    s16x8 wfr[2][4];                                                    // [half step s][n16 block j]
     auto load_w = [&](auto s_c, int kt) {
         constexpr int S = decltype(s_c)::value;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wfr[S][j] = *reinterpret_cast<const bf16x8*>(wf + j * wf_nb + (long)(kt * 2 + S) * 1024);
+        for (int j = 0; j < 4; ++j) wfr[S][j] = *reinterpret_cast<const s16x8*>(wf + j * wf_nb + (long)(kt * 2 + S) * 1024);
     };
     using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>;
 
@@ -386,23 +420,23 @@ __global__ void __launch_bounds__(256, 2) gemm_deform_bf16_v2_kernel(const GemmP
         load_w(C1{}, kt);
         if (kt + 2 < nk) gather_issue(CP{}, kt + 2);                      // set PAR held step kt: consumed by gather_finish in the previous iteration
         {
-            bf16x8 af[4];
+            s16x8 af[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(abuf + a_foff(i, 0));
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const s16x8*>(abuf + a_foff(i, 0));
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[0][j], af[i], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) acc[i][j] = BRN_MFMA_16X16X32(wfr[0][j], af[i], acc[i][j]);
         }
         if (kt + 1 < nk) load_w(C0{}, kt + 1);
         {
-            bf16x8 af[4];
+            s16x8 af[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(abuf + a_foff(i, 1));
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const s16x8*>(abuf + a_foff(i, 1));
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[1][j], af[i], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) acc[i][j] = BRN_MFMA_16X16X32(wfr[1][j], af[i], acc[i][j]);
         }
         if (kt + 1 < nk) gather_finish(CN{}, kt + 1, smem + (1 - PAR) * (DBM * DBK * 2));
         // offsets of block g are first read by gather_issue(kt' + 2) with kt' + 2 = g blk_steps; those of block g - 1 were last read by
@@ -450,7 +484,7 @@ __global__ void __launch_bounds__(256, 2) gemm_deform_bf16_v2_kernel(const GemmP
     }
     __syncthreads();
     {
-        __bf16* Cb = reinterpret_cast<__bf16*>(p.C);
+        s16_t* Cb = reinterpret_cast<s16_t*>(p.C);
 #pragma unroll
         for (int ps = 0; ps < DBM / 8; ++ps) {
             const int row = ps * 8 + (tid >> 5), c = tid & 31;
@@ -468,7 +502,7 @@ bool deform_bf16_eligible(const GemmParams& p) {
 }
 
 hipError_t launch_deform_bf16(const GemmParams& p, hipStream_t s) {
-    if (!deform_bf16_eligible(p) || p.M <= 0) return hipErrorInvalidValue;
+    if (!BRN_S16_SELF(deform_bf16_eligible)(p) || p.M <= 0) return hipErrorInvalidValue;
     const int tiles = ((p.M + DBM - 1) / DBM) * ((p.N + DBN - 1) / DBN);
     // BRN_DEFORM_V=1: the round-3 kernel (every thread computes its own sampling parameters), for same-box A/B runs and the bit-equality test
     static const int ver = getenv("BRN_DEFORM_V") ? atoi(getenv("BRN_DEFORM_V")) : 2;
@@ -479,4 +513,7 @@ hipError_t launch_deform_bf16(const GemmParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
+#if BRN_S16_F16
+}  // namespace hf
+#endif
 }  // namespace brn

@@ -24,6 +24,19 @@ template <> __device__ __forceinline__ void st4<__bf16>(__bf16* p, f32x4 v) {
     *reinterpret_cast<bf16x4_e*>(p) = h;
 }
 
+typedef _Float16 f16x4_e __attribute__((ext_vector_type(4)));        // compute mode BRN_F16: the same kernels on fp16 maps (launcher flag bf16 == 2)
+template <> __device__ __forceinline__ f32x4 ld4<_Float16>(const _Float16* p) {
+    const f16x4_e h = *reinterpret_cast<const f16x4_e*>(p);
+    f32x4 r = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    return r;
+}
+template <> __device__ __forceinline__ void st4<_Float16>(_Float16* p, f32x4 v) {
+    f16x4_e h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[e] = (_Float16)v[e];
+    *reinterpret_cast<f16x4_e*>(p) = h;
+}
+
 static inline dim3 grid1d(size_t n, int block) {
     size_t g = (n + block - 1) / block;
     if (g > 65535u * 32u) g = 65535u * 32u;   // kernels grid-stride
@@ -71,9 +84,10 @@ __global__ void resize_nhwc_kernel(const T* __restrict__ x, int B, int Hin, int 
 }
 
 // bf16 maps, 8 channels (16 bytes) per lane: same arithmetic per element as the 4-wide form, half the memory instructions
-__global__ void resize_nhwc_bf16x8_kernel(const __bf16* __restrict__ x, int B, int Hin, int Win, int C8, int ldx, int x_coff,
-                                          __bf16* __restrict__ y, int Hout, int Wout, int ldy, int y_coff) {
-    typedef __bf16 bf16x8_e __attribute__((ext_vector_type(8)));
+template <class E = __bf16>
+__global__ void resize_nhwc_bf16x8_kernel(const E* __restrict__ x, int B, int Hin, int Win, int C8, int ldx, int x_coff,
+                                          E* __restrict__ y, int Hout, int Wout, int ldy, int y_coff) {
+    typedef E bf16x8_e __attribute__((ext_vector_type(8)));
     const size_t total = (size_t)B * Hout * Wout * C8;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int c8 = (int)(idx % C8);
@@ -84,7 +98,7 @@ __global__ void resize_nhwc_bf16x8_kernel(const __bf16* __restrict__ x, int B, i
         int y0, y1, x0, x1; float ly, lx;
         ac_coord(oy, Hin, Hout, y0, y1, ly);
         ac_coord(ox, Win, Wout, x0, x1, lx);
-        const __bf16* base = x + (size_t)b * Hin * Win * ldx + x_coff + c8 * 8;
+        const E* base = x + (size_t)b * Hin * Win * ldx + x_coff + c8 * 8;
         const bf16x8_e v00 = *reinterpret_cast<const bf16x8_e*>(base + ((size_t)y0 * Win + x0) * ldx);
         const bf16x8_e v01 = *reinterpret_cast<const bf16x8_e*>(base + ((size_t)y0 * Win + x1) * ldx);
         const bf16x8_e v10 = *reinterpret_cast<const bf16x8_e*>(base + ((size_t)y1 * Win + x0) * ldx);
@@ -94,7 +108,7 @@ __global__ void resize_nhwc_bf16x8_kernel(const __bf16* __restrict__ x, int B, i
         for (int e = 0; e < 8; ++e) {
             const float a = (float)v00[e], bq = (float)v01[e], c = (float)v10[e], d = (float)v11[e];
             const float top = a + (bq - a) * lx, bot = c + (d - c) * lx;
-            r[e] = (__bf16)(top + (bot - top) * ly);
+            r[e] = (E)(top + (bot - top) * ly);
         }
         *reinterpret_cast<bf16x8_e*>(y + (((size_t)b * Hout + oy) * Wout + ox) * ldy + y_coff + c8 * 8) = r;
     }
@@ -110,8 +124,13 @@ hipError_t launch_resize_nhwc(const float* x, int B, int Hin, int Win, int C, in
         return hipGetLastError();
     }
     const size_t total = (size_t)B * Hout * Wout * (C / 4);
-    if (bf16 && ((C | ldx | ldy | x_coff | y_coff) & 7) == 0)
-        hipLaunchKernelGGL(resize_nhwc_bf16x8_kernel, grid1d(total / 2, 256), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x), B, Hin, Win, C / 8,
+    if (bf16 == 2 && ((C | ldx | ldy | x_coff | y_coff) & 7) == 0)
+        hipLaunchKernelGGL(resize_nhwc_bf16x8_kernel<_Float16>, grid1d(total / 2, 256), dim3(256), 0, s, reinterpret_cast<const _Float16*>(x), B, Hin, Win, C / 8,
+                           ldx, x_coff, reinterpret_cast<_Float16*>(y), Hout, Wout, ldy, y_coff);
+    else if (bf16 == 2) hipLaunchKernelGGL(resize_nhwc_kernel<_Float16>, grid1d(total, 256), dim3(256), 0, s, reinterpret_cast<const _Float16*>(x), B, Hin, Win, C / 4,
+                                 ldx, x_coff, reinterpret_cast<_Float16*>(y), Hout, Wout, ldy, y_coff);
+    else if (bf16 && ((C | ldx | ldy | x_coff | y_coff) & 7) == 0)
+        hipLaunchKernelGGL(resize_nhwc_bf16x8_kernel<__bf16>, grid1d(total / 2, 256), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x), B, Hin, Win, C / 8,
                            ldx, x_coff, reinterpret_cast<__bf16*>(y), Hout, Wout, ldy, y_coff);
     else if (bf16) hipLaunchKernelGGL(resize_nhwc_kernel<__bf16>, grid1d(total, 256), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x), B, Hin, Win, C / 4,
                                  ldx, x_coff, reinterpret_cast<__bf16*>(y), Hout, Wout, ldy, y_coff);
@@ -165,7 +184,8 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, int C, int HW, 
 hipError_t launch_nchw_to_nhwc(const float* x, int B, int C, int H, int W, float* y, int ldy, int y_coff, hipStream_t s, int bf16) {
     const int HW = H * W;
     dim3 grid((HW + 31) / 32, (C + 31) / 32, B);
-    if (bf16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<__bf16>, grid, dim3(256), 0, s, x, C, HW, reinterpret_cast<__bf16*>(y), ldy, y_coff);
+    if (bf16 == 2) hipLaunchKernelGGL(nchw_to_nhwc_kernel<_Float16>, grid, dim3(256), 0, s, x, C, HW, reinterpret_cast<_Float16*>(y), ldy, y_coff);
+    else if (bf16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<__bf16>, grid, dim3(256), 0, s, x, C, HW, reinterpret_cast<__bf16*>(y), ldy, y_coff);
     else hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, s, x, C, HW, y, ldy, y_coff);
     return hipGetLastError();
 }
@@ -188,7 +208,8 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, int C, int HW, int 
 hipError_t launch_nhwc_to_nchw(const float* x, int B, int C, int H, int W, int ldx, int x_coff, float* y, hipStream_t s, int bf16) {
     const int HW = H * W;
     dim3 grid((HW + 31) / 32, (C + 31) / 32, B);
-    if (bf16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<__bf16>, grid, dim3(256), 0, s, reinterpret_cast<const __bf16*>(x), C, HW, ldx, x_coff, y);
+    if (bf16 == 2) hipLaunchKernelGGL(nhwc_to_nchw_kernel<_Float16>, grid, dim3(256), 0, s, reinterpret_cast<const _Float16*>(x), C, HW, ldx, x_coff, y);
+    else if (bf16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<__bf16>, grid, dim3(256), 0, s, reinterpret_cast<const __bf16*>(x), C, HW, ldx, x_coff, y);
     else hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, s, x, C, HW, ldx, x_coff, y);
     return hipGetLastError();
 }
@@ -233,7 +254,8 @@ hipError_t launch_image2patches(const float* x, int B, int Cimg, int H, int W, i
     if (H % th || W % tw) return hipErrorInvalidValue;
     const size_t blocks = (size_t)B * th * ((tw + I2P_T - 1) / I2P_T) * ((cpad + I2P_T - 1) / I2P_T);
     if (blocks > 0x7fffffffu) return hipErrorInvalidValue;
-    if (bf16) hipLaunchKernelGGL(image2patches_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, x, B, Cimg, H, W, th, tw, reinterpret_cast<__bf16*>(y), ldy, cpad);
+    if (bf16 == 2) hipLaunchKernelGGL(image2patches_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, s, x, B, Cimg, H, W, th, tw, reinterpret_cast<_Float16*>(y), ldy, cpad);
+    else if (bf16) hipLaunchKernelGGL(image2patches_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, x, B, Cimg, H, W, th, tw, reinterpret_cast<__bf16*>(y), ldy, cpad);
     else hipLaunchKernelGGL(image2patches_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, x, B, Cimg, H, W, th, tw, y, ldy, cpad);
     return hipGetLastError();
 }
@@ -265,7 +287,8 @@ __global__ void gap_final_kernel(const float* __restrict__ part, int nchunks, in
 size_t gap_scratch_floats(int B, int HW, int C) { return (size_t)B * ((HW + GAP_CHUNK - 1) / GAP_CHUNK) * C; }
 hipError_t launch_gap_nhwc(const float* x, int B, int HW, int C, int ldx, int x_coff, float* scratch, float* out, hipStream_t s, int bf16) {
     const int nchunks = (HW + GAP_CHUNK - 1) / GAP_CHUNK;
-    if (bf16) hipLaunchKernelGGL(gap_partial_kernel<__bf16>, dim3((C + 63) / 64, nchunks, B), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x), HW, C, ldx, x_coff, scratch);
+    if (bf16 == 2) hipLaunchKernelGGL(gap_partial_kernel<_Float16>, dim3((C + 63) / 64, nchunks, B), dim3(256), 0, s, reinterpret_cast<const _Float16*>(x), HW, C, ldx, x_coff, scratch);
+    else if (bf16) hipLaunchKernelGGL(gap_partial_kernel<__bf16>, dim3((C + 63) / 64, nchunks, B), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x), HW, C, ldx, x_coff, scratch);
     else hipLaunchKernelGGL(gap_partial_kernel<float>, dim3((C + 63) / 64, nchunks, B), dim3(256), 0, s, x, HW, C, ldx, x_coff, scratch);
     hipLaunchKernelGGL(gap_final_kernel, dim3((C + 63) / 64, B), dim3(64), 0, s, scratch, nchunks, C, HW, out);
     return hipGetLastError();
@@ -317,7 +340,9 @@ hipError_t launch_gdt_gate(float* p, int npix, int C, int ldp, int p_coff, const
     if (C % 4) return hipErrorInvalidValue;
     size_t blocks = ((size_t)npix + 3) / 4;
     if (blocks > 8192) blocks = 8192;
-    if (bf16) hipLaunchKernelGGL(gdt_gate_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<__bf16*>(p), (size_t)npix, C / 4, ldp, p_coff,
+    if (bf16 == 2) hipLaunchKernelGGL(gdt_gate_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<_Float16*>(p), (size_t)npix, C / 4, ldp, p_coff,
+                                 reinterpret_cast<const _Float16*>(g), ldg, w, bias);
+    else if (bf16) hipLaunchKernelGGL(gdt_gate_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<__bf16*>(p), (size_t)npix, C / 4, ldp, p_coff,
                                  reinterpret_cast<const __bf16*>(g), ldg, w, bias);
     else hipLaunchKernelGGL(gdt_gate_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, p, (size_t)npix, C / 4, ldp, p_coff, g, ldg, w, bias);
     return hipGetLastError();
@@ -347,7 +372,8 @@ hipError_t launch_pixel_dot(const float* x, int npix, int C, int ldx, int x_coff
     if (C % 4) return hipErrorInvalidValue;
     size_t blocks = ((size_t)npix * 16 + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    if (bf16) hipLaunchKernelGGL(pixel_dot_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x), (size_t)npix, C / 4, ldx, x_coff, w, bias, y);
+    if (bf16 == 2) hipLaunchKernelGGL(pixel_dot_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const _Float16*>(x), (size_t)npix, C / 4, ldx, x_coff, w, bias, y);
+    else if (bf16) hipLaunchKernelGGL(pixel_dot_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x), (size_t)npix, C / 4, ldx, x_coff, w, bias, y);
     else hipLaunchKernelGGL(pixel_dot_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, x, (size_t)npix, C / 4, ldx, x_coff, w, bias, y);
     return hipGetLastError();
 }
@@ -383,20 +409,24 @@ hipError_t launch_final_head(const float* q, int B, int h, int w, const float* t
 }
 
 // fp32 -> bf16 (RNE) of a contiguous buffer: the op-level entry points in compute mode BRN_BF16 convert their operands at the edge
-__global__ void f32_to_bf16_kernel(const float* __restrict__ x, size_t n, __bf16* __restrict__ y) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = (__bf16)x[i];
+template <class E>
+__global__ void f32_to_bf16_kernel(const float* __restrict__ x, size_t n, E* __restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = (E)x[i];
 }
-hipError_t launch_f32_to_bf16(const float* x, size_t n, float* y_bf16, hipStream_t s) {
-    hipLaunchKernelGGL(f32_to_bf16_kernel, grid1d(n, 256), dim3(256), 0, s, x, n, reinterpret_cast<__bf16*>(y_bf16));
+hipError_t launch_f32_to_bf16(const float* x, size_t n, float* y_bf16, hipStream_t s, int f16) {
+    if (f16) hipLaunchKernelGGL(f32_to_bf16_kernel<_Float16>, grid1d(n, 256), dim3(256), 0, s, x, n, reinterpret_cast<_Float16*>(y_bf16));
+    else hipLaunchKernelGGL(f32_to_bf16_kernel<__bf16>, grid1d(n, 256), dim3(256), 0, s, x, n, reinterpret_cast<__bf16*>(y_bf16));
     return hipGetLastError();
 }
 
 // bf16 -> fp32 of a contiguous buffer (op-level entry points that hand a bf16 result back across the fp32 boundary)
-__global__ void bf16_to_f32_kernel(const __bf16* __restrict__ x, size_t n, float* __restrict__ y) {
+template <class E>
+__global__ void bf16_to_f32_kernel(const E* __restrict__ x, size_t n, float* __restrict__ y) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = (float)x[i];
 }
-hipError_t launch_bf16_to_f32(const float* x_bf16, size_t n, float* y, hipStream_t s) {
-    hipLaunchKernelGGL(bf16_to_f32_kernel, grid1d(n, 256), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x_bf16), n, y);
+hipError_t launch_bf16_to_f32(const float* x_bf16, size_t n, float* y, hipStream_t s, int f16) {
+    if (f16) hipLaunchKernelGGL(bf16_to_f32_kernel<_Float16>, grid1d(n, 256), dim3(256), 0, s, reinterpret_cast<const _Float16*>(x_bf16), n, y);
+    else hipLaunchKernelGGL(bf16_to_f32_kernel<__bf16>, grid1d(n, 256), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x_bf16), n, y);
     return hipGetLastError();
 }
 

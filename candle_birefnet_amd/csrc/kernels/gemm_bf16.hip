@@ -22,17 +22,55 @@
 #include "split_planes.h"
 #include <type_traits>
 
+// The file is compiled twice (Makefile): as is for compute mode BRN_BF16, and with -DBRN_S16_F16=1 for BRN_F16 — the same kernels with fp16
+// as the 16-bit storage / MFMA operand type (3 more mantissa bits at the same bytes and the same matrix rate), in namespace brn::hf.
+#ifndef BRN_S16_F16
+#define BRN_S16_F16 0
+#endif
 namespace brn {
+#if BRN_S16_F16
+namespace hf {
+typedef _Float16 s16_t;
+#define BRN_MFMA_32X32X16(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0)
+#define BRN_MFMA_16X16X32(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, C, 0, 0, 0)
+#else
+typedef __bf16 s16_t;
+#define BRN_MFMA_32X32X16(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
+#define BRN_MFMA_16X16X32(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, C, 0, 0, 0)
+#endif
+typedef s16_t s16x8 __attribute__((ext_vector_type(8)));
+#if BRN_S16_F16      // (an unqualified call would also find the brn:: function of the same name through its brn::GemmParams argument)
+#define BRN_S16_SELF(FN) hf::FN
+#else
+#define BRN_S16_SELF(FN) FN
+#endif
 
 typedef float f32x16_b __attribute__((ext_vector_type(16)));
 typedef float f32x4_b __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4_b __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2_b __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {      // v_cvt_pk_bf16_f32 (round to nearest even): lo in bits 0-15
-    typedef __bf16 bf16x2_b __attribute__((ext_vector_type(2)));
-    const bf16x2_b t = {(__bf16)lo, (__bf16)hi};
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {      // v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 (round to nearest even): lo in bits 0-15
+    typedef s16_t s16x2_b __attribute__((ext_vector_type(2)));
+    const s16x2_b t = {(s16_t)lo, (s16_t)hi};
     return __builtin_bit_cast(unsigned, t);
+}
+// the two 16-bit storage values packed in a dword, as fp32
+__device__ __forceinline__ float s16_lo_f32(unsigned r) {
+#if BRN_S16_F16
+    typedef _Float16 h2_b __attribute__((ext_vector_type(2)));
+    return (float)__builtin_bit_cast(h2_b, r)[0];
+#else
+    return __builtin_bit_cast(float, r << 16);
+#endif
+}
+__device__ __forceinline__ float s16_hi_f32(unsigned r) {
+#if BRN_S16_F16
+    typedef _Float16 h2_b __attribute__((ext_vector_type(2)));
+    return (float)__builtin_bit_cast(h2_b, r)[1];
+#else
+    return __builtin_bit_cast(float, r & 0xffff0000u);
+#endif
 }
 
 __device__ __attribute__((aligned(16))) unsigned g_zero_page[64];   // 256 zero bytes (code-object global: zero-initialised)
@@ -62,7 +100,8 @@ __device__ __forceinline__ float gelu_erf_b(float x) {   // same fit as gemm_f32
 // undoes — ONE transcendental instead of two, 1 clamp + 5 fma + v_exp + max + fma = 12 issue slots instead of 17, and a better fit:
 // weighted least squares on [0, 8] (weights = the tolerance budget below; coefficients rounded to fp32 and the whole form re-evaluated in
 // emulated fp32 over 5e6 points of [-40, 40]): |gelu error| < 3.0e-6 absolute and < 5.2e-5 relative for |gelu| >= 1e-2 — a hundredth of
-// half a bf16 ulp.  Beyond u = 8 the clamp holds h at 2^-51.9: |x| h is below 1e-7 for every |x| < 1e9.
+// half a bf16 ulp (a fifth of half an fp16 ulp: the fp16 build, compute mode BRN_F16, keeps the form).  Beyond u = 8 the clamp holds h at
+// 2^-51.9: |x| h is below 1e-7 for every |x| < 1e9.
 __device__ __forceinline__ float gelu_erf_bf16out(float x) {
     const float ax = fabsf(x);
     float u, r;
@@ -114,7 +153,7 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned vof
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 __device__ __forceinline__ f32x4_b zero4b() { f32x4_b z = {0.f, 0.f, 0.f, 0.f}; return z; }
-__device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) { return s16_lo_f32((unsigned)h); }
 
 // 8 consecutive outputs of one row: everything of the epilogue after the accumulator
 template <bool VEC>
@@ -144,8 +183,8 @@ __device__ __forceinline__ void store_row8(const GemmParams& p, int m, int n, fl
                 const u32x4_b r = *reinterpret_cast<const u32x4_b*>(rp);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[2 * e] += __builtin_bit_cast(float, r[e] << 16);
-                    v[2 * e + 1] += __builtin_bit_cast(float, r[e] & 0xffff0000u);
+                    v[2 * e] += s16_lo_f32(r[e]);
+                    v[2 * e + 1] += s16_hi_f32(r[e]);
                 }
             } else {
 #pragma unroll
@@ -164,15 +203,15 @@ __device__ __forceinline__ void store_row8(const GemmParams& p, int m, int n, fl
             for (int e = 0; e < 8; ++e) if (n + e < p.N) dst[e] = v[e];
         }
     } else {
-        __bf16* dst = reinterpret_cast<__bf16*>(p.C) + (long)m * p.ldc + p.c_coff + n;
+        s16_t* dst = reinterpret_cast<s16_t*>(p.C) + (long)m * p.ldc + p.c_coff + n;
         if (VEC) {
-            bf16x8 o;
+            s16x8 o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
-            *reinterpret_cast<bf16x8*>(dst) = o;
+            for (int e = 0; e < 8; ++e) o[e] = (s16_t)v[e];
+            *reinterpret_cast<s16x8*>(dst) = o;
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) if (n + e < p.N) dst[e] = (__bf16)v[e];
+            for (int e = 0; e < 8; ++e) if (n + e < p.N) dst[e] = (s16_t)v[e];
         }
     }
 }
@@ -250,8 +289,8 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
     const int lrow = RPB * pr0 + qs / CPR;                      // tile row of instruction j = 0; + RPI NW per further instruction
     const int kch = (qs % CPR) * 8;                             // first k (within the K step) of this lane's chunk
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
-    const __bf16* Ab = reinterpret_cast<const __bf16*>(p.A);
-    const __bf16* Wb = reinterpret_cast<const __bf16*>(p.Wp);
+    const s16_t* Ab = reinterpret_cast<const s16_t*>(p.A);
+    const s16_t* Wb = reinterpret_cast<const s16_t*>(p.Wp);
 
     // fragment addressing: 32x32x16: lane reads row (lane & 31) of a 32-row block, logical chunk 2 s + (lane >> 5) at k16 step s;
     // 16x16x32: row (lane & 15) of a 16-row block, chunk 4 s + (lane >> 4) at k32 step s.  With 128-byte tile rows a 16-row block is 8
@@ -277,8 +316,8 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
     int c_ci = 0, c_ky = 0, c_kx = 0;      // conv: (tap, channel) of this lane's chunk, advanced by BBK channels per K step
     long w_off0 = 0;
     // FAST: buffer resources based at (row m0, k = kt0 * BBK) of A / (row n0, same k) of W: `buffer_load_dwordx4 v_off, s[rsrc], s_koff offen lds`
-    __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Ab), 0, 0x7fffffff, 0x00020000);
-    __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Wb), 0, 0x7fffffff, 0x00020000);
+    __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<s16_t*>(Ab), 0, 0x7fffffff, 0x00020000);
+    __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<s16_t*>(Wb), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
     for (int j = 0; j < LB; ++j) w_voff[j] = (unsigned)(((lrow + RPI * NW * j) * p.wp_ld + kch) * 2);
     auto setup = [&](int work) {
@@ -324,14 +363,14 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
             c_ky = tap / p.kw; c_kx = tap - c_ky * p.kw;
             tap_off = ((c_ky * p.dil) * p.Win + c_kx * p.dil) * p.lda * 2 + c_ci * 2;
             const int b0 = min(m0, p.M - 1) / (p.Hout * p.Wout);
-            a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Ab + (long)b0 * p.Hin * p.Win * p.lda + p.a_coff), 0, 0x7fffffff, 0x00020000);
-            w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Wb + (long)n0 * p.wp_ld + (long)kt0 * BBK), 0, 0x7fffffff, 0x00020000);
+            a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<s16_t*>(Ab + (long)b0 * p.Hin * p.Win * p.lda + p.a_coff), 0, 0x7fffffff, 0x00020000);
+            w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<s16_t*>(Wb + (long)n0 * p.wp_ld + (long)kt0 * BBK), 0, 0x7fffffff, 0x00020000);
         }
         // W rows n0 + lrow + RPI NW j of the padded [rows][wp_ld] bf16 matrix (rows and K zero-padded to the tile: always in bounds)
         w_off0 = (long)(n0 + lrow) * p.wp_ld + kch;
         if (FAST) {
-            a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Ab + (long)m0 * p.lda + p.a_coff + (long)kt0 * BBK), 0, 0x7fffffff, 0x00020000);
-            w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Wb + (long)n0 * p.wp_ld + (long)kt0 * BBK), 0, 0x7fffffff, 0x00020000);
+            a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<s16_t*>(Ab + (long)m0 * p.lda + p.a_coff + (long)kt0 * BBK), 0, 0x7fffffff, 0x00020000);
+            w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<s16_t*>(Wb + (long)n0 * p.wp_ld + (long)kt0 * BBK), 0, 0x7fffffff, 0x00020000);
         }
     };
     // piece j of K step t (local index) into ring slot t % NSTAGE: j < LA = A rows, else W rows; stage_advance() after the last piece
@@ -418,7 +457,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
         static_assert(NSTAGE == 2 && KSUB >= 2 && KSUB % 2 == 0, "two ring slots, an even number of sub-steps per K step");
         constexpr int NF = FM + FN, NM = FM * FN;                  // fragment reads and MFMAs per sub-step (k16 / k32)
         static_assert(NM >= LPS && NM >= NF, "a sub-step has fewer MFMAs than LDS operations to place between them");
-        bf16x8 af[2][FM], bf[2][FN];
+        s16x8 af[2][FM], bf[2][FN];
         // fragment f of sub-step s from ring slot `sb`: A blocks 0 .. FM-1, W blocks FM .. NF-1
         auto frag_offsets = [&](int (&foff)[KSUB]) {
             int flane = lane;
@@ -429,10 +468,10 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
             for (int q = 0; q < KSUB; ++q) foff[q] = (frow / RPB) * 256 + ((((frow % RPB) * CPR + ((M16 ? 4 : 2) * q + fh)) ^ fswz) << 4);
         };
         auto read_a = [&](const char* sb, const int (&foff)[KSUB], int sub, int f) {
-            af[sub & 1][f] = *reinterpret_cast<const bf16x8*>(sb + a_base + f * (FR * ROWB) + (foff[sub] ^ ((f & 1) ? ODD_FLIP : 0)));
+            af[sub & 1][f] = *reinterpret_cast<const s16x8*>(sb + a_base + f * (FR * ROWB) + (foff[sub] ^ ((f & 1) ? ODD_FLIP : 0)));
         };
         auto read_b = [&](const char* sb, const int (&foff)[KSUB], int sub, int f) {
-            bf[sub & 1][f] = *reinterpret_cast<const bf16x8*>(sb + b_base + f * (FR * ROWB) + (foff[sub] ^ ((f & 1) ? ODD_FLIP : 0)));
+            bf[sub & 1][f] = *reinterpret_cast<const s16x8*>(sb + b_base + f * (FR * ROWB) + (foff[sub] ^ ((f & 1) ? ODD_FLIP : 0)));
         };
         // one sub-step: NM MFMAs on register set S & 1; after MFMA m, in this order: the A fragment m (m < FM) and the W fragment of the
         // next sub-step (BSINGLE: W block m / FM right after its last use, MFMA order W block outer; else W fragment m - FM), then
@@ -450,8 +489,8 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
             static_for<0, NM>([&](auto mc) {                      // transposed product: W fragment first
                 constexpr int Mi = decltype(mc)::value;
                 constexpr int i = BSINGLE ? Mi % FM : Mi / FN, j = BSINGLE ? Mi / FM : Mi % FN;
-                if constexpr (M16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[S & 1][j], af[S & 1][i], acc[i][j], 0, 0, 0);
-                else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[S & 1][j], af[S & 1][i], acc[i][j], 0, 0, 0);
+                if constexpr (M16) acc[i][j] = BRN_MFMA_16X16X32(bf[S & 1][j], af[S & 1][i], acc[i][j]);
+                else acc[i][j] = BRN_MFMA_32X32X16(bf[S & 1][j], af[S & 1][i], acc[i][j]);
             });
             if (STAGE) stage_advance();
             if (SCHED) {
@@ -652,10 +691,10 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
                                 if (p.R) {                           // bf16 residual (the decoder's lateral adds, in place)
                                     const char* rp = ru + (long)(ps * RPP) * p.ldr * 2 + roff;
                                     const u32x4_b rr = *reinterpret_cast<const u32x4_b*>(ok ? rp : reinterpret_cast<const char*>(g_zero_page));
-                                    a[0] += __builtin_bit_cast(float, rr[0] << 16); a[1] += __builtin_bit_cast(float, rr[0] & 0xffff0000u);
-                                    a[2] += __builtin_bit_cast(float, rr[1] << 16); a[3] += __builtin_bit_cast(float, rr[1] & 0xffff0000u);
-                                    b[0] += __builtin_bit_cast(float, rr[2] << 16); b[1] += __builtin_bit_cast(float, rr[2] & 0xffff0000u);
-                                    b[2] += __builtin_bit_cast(float, rr[3] << 16); b[3] += __builtin_bit_cast(float, rr[3] & 0xffff0000u);
+                                    a[0] += s16_lo_f32(rr[0]); a[1] += s16_hi_f32(rr[0]);
+                                    a[2] += s16_lo_f32(rr[1]); a[3] += s16_hi_f32(rr[1]);
+                                    b[0] += s16_lo_f32(rr[2]); b[1] += s16_hi_f32(rr[2]);
+                                    b[2] += s16_lo_f32(rr[3]); b[3] += s16_hi_f32(rr[3]);
                                 }
                                 const u32x4_b o = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
                                 if (!(abl & 16) || a[0] == 123.456f)  // diag bit 16: the epilogue without its stores
@@ -705,9 +744,11 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_bf16_kernel(const GemmParams
 constexpr int WSTAT_WG_PER_CU = 2;      // 2: <= 256 VGPRs, no spill (forced to 168 for three per CU the kernel spills 30-40 registers)
 // CUs the persistent grids of this file are sized for: 256, or the size of the CU mask of the stream being launched on (a sub-batch
 // stream confined to a part of the chip, brn_api.cpp run_model); thread-local: set by the host thread that enqueues the forward
+#if !BRN_S16_F16     // (one state for both builds: brn::launch_cus)
 static thread_local int g_launch_cus = 256;
 int launch_cus() { return g_launch_cus; }
 void set_launch_cus(int n) { g_launch_cus = n < 8 ? 8 : (n > 256 ? 256 : n) / 8 * 8; }
+#endif
 
 __device__ __forceinline__ int ws_slot(int r, int c) { return (r >> 1) * 256 + (((((r & 1) << 3) | c) ^ ((r >> 1) & 15)) << 4); }
 
@@ -731,13 +772,13 @@ __global__ void __launch_bounds__(256, 2) gemm_wstat_bf16_kernel(const GemmParam
     if (wk >= nw) return;
     const int n0 = grp * WBN + wave * 48;                               // this wave's first column
     // ---- W fragments, resident for the whole launch ----
-    bf16x8 wfr[3][K32];
+    s16x8 wfr[3][K32];
     {
         const char* wf = reinterpret_cast<const char*>(p.Wp) + ((long)(n0 >> 4) * K32 * 64 + lane) * 16;
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int ks = 0; ks < K32; ++ks) wfr[j][ks] = *reinterpret_cast<const bf16x8*>(wf + (long)(j * K32 + ks) * 1024);
+            for (int ks = 0; ks < K32; ++ks) wfr[j][ks] = *reinterpret_cast<const s16x8*>(wf + (long)(j * K32 + ks) * 1024);
     }
     f32x4_b bias[3];
 #pragma unroll
@@ -751,10 +792,10 @@ __global__ void __launch_bounds__(256, 2) gemm_wstat_bf16_kernel(const GemmParam
         a_row[j] = 2 * pr + (qs >> 3);
         a_voff[j] = (unsigned)((qs & 7) * 16);                          // byte offset inside the 128-byte K-step piece of the row
     }
-    const __bf16* Ab = reinterpret_cast<const __bf16*>(p.A);
+    const s16_t* Ab = reinterpret_cast<const s16_t*>(p.A);
     auto issue = [&](int t, char* buf) {
         const int m0 = t * WBM;
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Ab + (long)m0 * p.lda + p.a_coff), 0, 0x7fffffff, 0x00020000);
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<s16_t*>(Ab + (long)m0 * p.lda + p.a_coff), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const unsigned ro = (unsigned)((min(m0 + a_row[j], p.M - 1) - m0) * p.lda * 2) + a_voff[j];   // rows >= M re-read row M - 1 (never stored)
@@ -783,18 +824,18 @@ __global__ void __launch_bounds__(256, 2) gemm_wstat_bf16_kernel(const GemmParam
             for (int j = 0; j < 3; ++j) acc[i][j] = zero4b();
 #pragma unroll
         for (int ks = 0; ks < K32; ++ks) {
-            bf16x8 af[RF];
+            s16x8 af[RF];
 #pragma unroll
-            for (int i = 0; i < RF; ++i) af[i] = *reinterpret_cast<const bf16x8*>(buf + (ks >> 1) * SUB + a_foff[i][ks & 1]);
+            for (int i = 0; i < RF; ++i) af[i] = *reinterpret_cast<const s16x8*>(buf + (ks >> 1) * SUB + a_foff[i][ks & 1]);
 #pragma unroll
             for (int j = 0; j < 3; ++j)
 #pragma unroll
-                for (int i = 0; i < RF; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[j][ks], af[i], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < RF; ++i) acc[i][j] = BRN_MFMA_16X16X32(wfr[j][ks], af[i], acc[i][j]);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                   // every wave has read its fragments: the buffer now takes the C tile
         const int m0 = t * WBM;
-        __bf16* Cb = reinterpret_cast<__bf16*>(p.C);
+        s16_t* Cb = reinterpret_cast<s16_t*>(p.C);
 #pragma unroll
         for (int half = 0; half < WBM / 32; ++half) {
 #pragma unroll
@@ -837,7 +878,7 @@ __global__ void __launch_bounds__(256, 2) gemm_wstat_bf16_kernel(const GemmParam
 // layernorm_kernel) over the 8 lanes by DPP shuffles, store of y.  What it saves is the stand-alone LayerNorm's read of x.
 // =====================================================================================================================
 __global__ void __launch_bounds__(256, 2) gemm_wstat_ln_bf16_kernel(const GemmParams p, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                     const float eps, __bf16* __restrict__ Y, const int ldy) {
+                                                                     const float eps, s16_t* __restrict__ Y, const int ldy) {
     constexpr int KS = 3, WBM = 64, WBN = 192, SUB = WBM * 128;
     constexpr int K32 = KS * 2, ABUF = KS * SUB;
     static_assert(ABUF == 32 * WBN * 4, "a 32-row half of the fp32 C tile is exactly one A buffer");
@@ -850,13 +891,13 @@ __global__ void __launch_bounds__(256, 2) gemm_wstat_ln_bf16_kernel(const GemmPa
     const int t_lo = (int)((long)T * xcd / 8), t_hi = (int)((long)T * (xcd + 1) / 8);
     if (tid < WBN) { gb_s[tid] = gamma[tid]; gb_s[WBN + tid] = beta[tid]; }
     const int n0 = wave * 48;
-    bf16x8 wfr[3][K32];
+    s16x8 wfr[3][K32];
     {
         const char* wf = reinterpret_cast<const char*>(p.Wp) + ((long)(n0 >> 4) * K32 * 64 + lane) * 16;
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int ks = 0; ks < K32; ++ks) wfr[j][ks] = *reinterpret_cast<const bf16x8*>(wf + (long)(j * K32 + ks) * 1024);
+            for (int ks = 0; ks < K32; ++ks) wfr[j][ks] = *reinterpret_cast<const s16x8*>(wf + (long)(j * K32 + ks) * 1024);
     }
     f32x4_b bias[3];
 #pragma unroll
@@ -869,10 +910,10 @@ __global__ void __launch_bounds__(256, 2) gemm_wstat_ln_bf16_kernel(const GemmPa
         a_row[j] = 2 * pr + (qs >> 3);
         a_voff[j] = (unsigned)((qs & 7) * 16);
     }
-    const __bf16* Ab = reinterpret_cast<const __bf16*>(p.A);
+    const s16_t* Ab = reinterpret_cast<const s16_t*>(p.A);
     auto issue = [&](int t, char* buf) {
         const int m0 = t * WBM;
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Ab + (long)m0 * p.lda + p.a_coff), 0, 0x7fffffff, 0x00020000);
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<s16_t*>(Ab + (long)m0 * p.lda + p.a_coff), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const unsigned ro = (unsigned)((min(m0 + a_row[j], p.M - 1) - m0) * p.lda * 2) + a_voff[j];
@@ -904,13 +945,13 @@ __global__ void __launch_bounds__(256, 2) gemm_wstat_ln_bf16_kernel(const GemmPa
             for (int j = 0; j < 3; ++j) acc[i][j] = zero4b();
 #pragma unroll
         for (int ks = 0; ks < K32; ++ks) {
-            bf16x8 af[4];
+            s16x8 af[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(buf + (ks >> 1) * SUB + a_foff[i][ks & 1]);
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const s16x8*>(buf + (ks >> 1) * SUB + a_foff[i][ks & 1]);
 #pragma unroll
             for (int j = 0; j < 3; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[j][ks], af[i], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) acc[i][j] = BRN_MFMA_16X16X32(wfr[j][ks], af[i], acc[i][j]);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                   // every wave has read its fragments: the buffer now takes the C tile
@@ -985,7 +1026,7 @@ __global__ void __launch_bounds__(256, 2) gemm_wstat_ln_bf16_kernel(const GemmPa
 // =====================================================================================================================
 template <int NC>
 __global__ void __launch_bounds__(512) gemm_rowln_bf16_kernel(const GemmParams p, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              const float eps, __bf16* __restrict__ Y, const int ldy) {
+                                                              const float eps, s16_t* __restrict__ Y, const int ldy) {
     constexpr int RBM = 64, RBK = 32, ROWB = RBK * 2;                    // 64-byte tile rows
     constexpr int WCOL = NC / 8;                                         // columns per wave: 96 / 48
     constexpr int FN = WCOL / 16, FM = RBM / 16;                         // 16 x 16 blocks of a wave tile
@@ -1001,8 +1042,8 @@ __global__ void __launch_bounds__(512) gemm_rowln_bf16_kernel(const GemmParams p
     const int xcd = blockIdx.x & 7, wk = blockIdx.x >> 3, nw = (int)gridDim.x >> 3;
     const int t_lo = (int)((long)T * xcd / 8), t_hi = (int)((long)T * (xcd + 1) / 8);
     const int nk = p.K / RBK;
-    const __bf16* Ab = reinterpret_cast<const __bf16*>(p.A);
-    const __bf16* Wb = reinterpret_cast<const __bf16*>(p.Wp);
+    const s16_t* Ab = reinterpret_cast<const s16_t*>(p.A);
+    const s16_t* Wb = reinterpret_cast<const s16_t*>(p.Wp);
 
     // ---- LDS-DMA: instruction ii fills bank rows 4 ii .. 4 ii + 3 (16 tile rows); lane -> (tile row, k chunk) through the swizzle ----
     const int pr_l = lane >> 4;
@@ -1010,7 +1051,7 @@ __global__ void __launch_bounds__(512) gemm_rowln_bf16_kernel(const GemmParams p
     const int qs = (lane & 15) ^ pr_l;
     const int row16 = 4 * pr_l + (qs >> 2);                              // row within a 16-row piece
     const unsigned kch_b = (unsigned)((qs & 3) * 16);                    // byte offset of the lane's k chunk within the 64-byte K step
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Wb), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<s16_t*>(Wb), 0, 0x7fffffff, 0x00020000);
     unsigned w_voff[LW];
 #pragma unroll
     for (int j = 0; j < LW; ++j) w_voff[j] = (unsigned)((16 * (wave * LW + j) + row16) * p.wp_ld * 2) + kch_b;
@@ -1018,7 +1059,7 @@ __global__ void __launch_bounds__(512) gemm_rowln_bf16_kernel(const GemmParams p
         char* sb = smem + slot * SLOT;
         if (wave < 4) {
             const int r = 16 * wave + row16;
-            const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Ab + (long)m0 * p.lda + p.a_coff), 0, 0x7fffffff, 0x00020000);
+            const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<s16_t*>(Ab + (long)m0 * p.lda + p.a_coff), 0, 0x7fffffff, 0x00020000);
             const unsigned vo = (unsigned)((min(m0 + r, p.M - 1) - m0) * p.lda * 2) + kch_b;     // rows >= M re-read row M - 1 (never stored)
             blds16(a_rsrc, vo, kt * ROWB, sb + wave * 1024);
         }
@@ -1045,15 +1086,15 @@ __global__ void __launch_bounds__(512) gemm_rowln_bf16_kernel(const GemmParams p
             __builtin_amdgcn_s_barrier();                                // everybody's pieces landed; everybody is done reading step kt - 1
             if (kt + 2 < nk) issue(m0, kt + 2, (kt + 4) % 3);            // into the slot step kt - 1 just left
             const char* sb = smem + ((kt + 2) % 3) * SLOT;
-            bf16x8 af[FM], bfr[FN];
+            s16x8 af[FM], bfr[FN];
 #pragma unroll
-            for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sb + i * 1024 + f_off);
+            for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const s16x8*>(sb + i * 1024 + f_off);
 #pragma unroll
-            for (int j = 0; j < FN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + A_BYTES + (wave * FN + j) * 1024 + f_off);
+            for (int j = 0; j < FN; ++j) bfr[j] = *reinterpret_cast<const s16x8*>(sb + A_BYTES + (wave * FN + j) * 1024 + f_off);
 #pragma unroll
             for (int j = 0; j < FN; ++j)
 #pragma unroll
-                for (int i = 0; i < FM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < FM; ++i) acc[i][j] = BRN_MFMA_16X16X32(bfr[j], af[i], acc[i][j]);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                    // every fragment read of the tile is done: the ring is free
@@ -1125,13 +1166,13 @@ bool gemm_rowln_eligible(const GemmParams& p) {
            p.wp_ld >= p.K && (p.wp_ld & 7) == 0 && (double)p.wp_ld * 2.0 * p.N < 2147483648.0 && (double)p.lda * 2.0 * 64 < 2147483648.0;
 }
 hipError_t launch_gemm_rowln(const GemmParams& p, const float* gamma, const float* beta, float eps, void* y_bf16, int ldy, hipStream_t s) {
-    if (!gemm_rowln_eligible(p) || !gamma || !beta || !y_bf16 || (ldy & 3)) return hipErrorInvalidValue;
+    if (!BRN_S16_SELF(gemm_rowln_eligible)(p) || !gamma || !beta || !y_bf16 || (ldy & 3)) return hipErrorInvalidValue;
     const int tiles = (p.M + 63) / 64;
     int g = launch_cus();
     if (g > tiles) g = (tiles + 7) / 8 * 8;
     dim3 grid(g), block(512);
-    if (p.N == 768) hipLaunchKernelGGL(gemm_rowln_bf16_kernel<768>, grid, block, 0, s, p, gamma, beta, eps, reinterpret_cast<__bf16*>(y_bf16), ldy);
-    else hipLaunchKernelGGL(gemm_rowln_bf16_kernel<384>, grid, block, 0, s, p, gamma, beta, eps, reinterpret_cast<__bf16*>(y_bf16), ldy);
+    if (p.N == 768) hipLaunchKernelGGL(gemm_rowln_bf16_kernel<768>, grid, block, 0, s, p, gamma, beta, eps, reinterpret_cast<s16_t*>(y_bf16), ldy);
+    else hipLaunchKernelGGL(gemm_rowln_bf16_kernel<384>, grid, block, 0, s, p, gamma, beta, eps, reinterpret_cast<s16_t*>(y_bf16), ldy);
     return hipGetLastError();
 }
 
@@ -1140,9 +1181,9 @@ bool gemm_wstat_ln_eligible(const GemmParams& p) {
            ((p.lda | p.a_coff) & 7) == 0 && ((p.ldc | p.c_coff | p.ldr | p.r_coff) & 3) == 0 && p.M >= 32768 && (long)p.lda * 2 * 64 < 0x7fffffffL;
 }
 hipError_t launch_gemm_wstat_ln(const GemmParams& p, const float* gamma, const float* beta, float eps, void* y_bf16, int ldy, hipStream_t s) {
-    if (!gemm_wstat_ln_eligible(p) || !gamma || !beta || !y_bf16 || (ldy & 3)) return hipErrorInvalidValue;
+    if (!BRN_S16_SELF(gemm_wstat_ln_eligible)(p) || !gamma || !beta || !y_bf16 || (ldy & 3)) return hipErrorInvalidValue;
     dim3 grid(8 * (launch_cus() * 2 / 8)), block(256);
-    hipLaunchKernelGGL(gemm_wstat_ln_bf16_kernel, grid, block, 0, s, p, gamma, beta, eps, reinterpret_cast<__bf16*>(y_bf16), ldy);
+    hipLaunchKernelGGL(gemm_wstat_ln_bf16_kernel, grid, block, 0, s, p, gamma, beta, eps, reinterpret_cast<s16_t*>(y_bf16), ldy);
     return hipGetLastError();
 }
 
@@ -1154,7 +1195,7 @@ bool gemm_wstat_eligible(const GemmParams& p) {
            ((p.lda | p.a_coff | p.ldc | p.c_coff) & 7) == 0 && p.M >= 32768 && (long)p.lda * 2 * 64 < 0x7fffffffL;
 }
 hipError_t launch_gemm_wstat(const GemmParams& p, hipStream_t s) {
-    if (!gemm_wstat_eligible(p)) return hipErrorInvalidValue;
+    if (!BRN_S16_SELF(gemm_wstat_eligible)(p)) return hipErrorInvalidValue;
     const int G = p.N / 192;
     const int nw = (launch_cus() * WSTAT_WG_PER_CU / 8) / G;
     if (nw < 1) return hipErrorInvalidValue;
@@ -1186,7 +1227,7 @@ __global__ void splitk_reduce_bf16_kernel(const GemmParams p) {
         if (p.R) v += p.r_f32 ? p.R[(long)m * p.ldr + p.r_coff + n]
                               : bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(p.R)[(long)m * p.ldr + p.r_coff + n]);
         if (p.c_f32) p.C[(long)m * p.ldc + p.c_coff + n] = v;
-        else reinterpret_cast<__bf16*>(p.C)[(long)m * p.ldc + p.c_coff + n] = (__bf16)v;
+        else reinterpret_cast<s16_t*>(p.C)[(long)m * p.ldc + p.c_coff + n] = (s16_t)v;
     }
 }
 
@@ -1286,4 +1327,7 @@ hipError_t launch_gemm_bf16(const GemmParams& p_in, const GemmPlan& pl, float* w
     return hipGetLastError();
 }
 
+#if BRN_S16_F16
+}  // namespace hf
+#endif
 }  // namespace brn

@@ -152,7 +152,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                 if (p.scale) v = v * sc + sh;
                 v = act4(v, p.act);
                 float* dst = p.C + (long)m * p.ldc + p.c_coff + n;
-                if (p.c_bf16) {                 // compute mode BRN_BF16 (deformable gather convs): bf16 map out, no residual on this path
+                if (p.c_bf16 == 2) {            // compute mode BRN_F16: fp16 map out
+                    _Float16* db = reinterpret_cast<_Float16*>(p.C) + (long)m * p.ldc + p.c_coff + n;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (n + e < p.N) db[e] = (_Float16)v[e];
+                } else if (p.c_bf16) {          // compute mode BRN_BF16 (deformable gather convs): bf16 map out, no residual on this path
                     __bf16* db = reinterpret_cast<__bf16*>(p.C) + (long)m * p.ldc + p.c_coff + n;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) if (n + e < p.N) db[e] = (__bf16)v[e];
@@ -312,6 +316,12 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_f32_kernel(const GemmParams 
                         // compute mode BRN_BF16: the sampled map is bf16 (lda / a_coff in elements either way)
                         auto tap4 = [&](int yy, int xx) -> f32x4 {
                             const long o = boff + ((long)yy * p.Win + xx) * p.lda;
+                            if (p.a_bf16 == 2) {               // compute mode BRN_F16: an fp16 map
+                                typedef _Float16 f16x4_g __attribute__((ext_vector_type(4)));
+                                const f16x4_g h = *reinterpret_cast<const f16x4_g*>(reinterpret_cast<const _Float16*>(p.A) + o);
+                                f32x4 r4 = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+                                return r4;
+                            }
                             if (p.a_bf16) {
                                 const bf16x4 h = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(p.A) + o);
                                 f32x4 r4 = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]};

@@ -72,10 +72,18 @@ __global__ void __launch_bounds__(LN_WAVES * 64) layernorm_kernel(const LayerNor
             if (p.y_planes && p.y_h2 > 0.f) store_planes_h(p.y + row * p.ldy, p.y_coff + c4 * 4, o, p.y_h2);   // consumer = an fp16-pair GEMM (mode f32_half2)
             else if (p.y_planes) store_planes_n(p.y_planes, p.y + row * p.ldy, p.y_coff + c4 * 4, o);   // consumer = a split-bf16 GEMM (P layout)
             else if (p.y_bf16) {                 // compute mode BRN_BF16: the consumer GEMM reads bf16 (ldy / y_coff in bf16 elements)
+                if (p.y_bf16 == 2) {             // compute mode BRN_F16: fp16
+                    typedef _Float16 f16x4_ln __attribute__((ext_vector_type(4)));
+                    f16x4_ln h;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h[e] = (_Float16)o[e];
+                    *reinterpret_cast<f16x4_ln*>(reinterpret_cast<_Float16*>(p.y) + row * p.ldy + p.y_coff + c4 * 4) = h;
+                } else {
                 bf16x4 h;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) h[e] = (__bf16)o[e];
                 *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.y) + row * p.ldy + p.y_coff + c4 * 4) = h;
+                }
             } else *reinterpret_cast<f32x4*>(yrow + c4 * 4) = o;
         }
     }

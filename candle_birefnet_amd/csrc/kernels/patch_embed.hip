@@ -18,7 +18,7 @@ __global__ void __launch_bounds__(256, 2) patch_embed_ln_kernel(const float* __r
                                                                 const float* __restrict__ wgt, const int ldw, const float* __restrict__ bias,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, const float eps,
                                                                 float* __restrict__ x, const int ldx, const int img_aligned16,
-                                                                const float* __restrict__ gamma1, const float* __restrict__ beta1, void* __restrict__ xn, const int ldxn) {
+                                                                const float* __restrict__ gamma1, const float* __restrict__ beta1, void* __restrict__ xn, const int ldxn, const int xn_f16) {
     __shared__ __attribute__((aligned(16))) float As[PE_TM * PE_LDA];    // [token][k = (c, ky, kx)]
     __shared__ __attribute__((aligned(16))) float Cs[32 * PE_N];         // a 32-row half of the C tile, 16-byte chunks XOR-ed with the row
     __shared__ __attribute__((aligned(16))) float gb_s[4 * PE_N];        // gamma | beta of PatchEmbed's norm, then of the first block's norm1 (optional)
@@ -143,11 +143,19 @@ __global__ void __launch_bounds__(256, 2) patch_embed_ln_kernel(const float* __r
                         const int c0 = (ec + 8 * k) * 4;
                         const f32x4_p gm = *reinterpret_cast<const f32x4_p*>(gb_s + 2 * PE_N + c0), bt = *reinterpret_cast<const f32x4_p*>(gb_s + 3 * PE_N + c0);
                         const f32x4_p o = xv[k] * rstd1 * gm + bt;
+                        if (xn_f16) {                 // compute mode BRN_F16
+                            typedef _Float16 f16x4_p __attribute__((ext_vector_type(4)));
+                            f16x4_p h;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) h[e] = (_Float16)o[e];
+                            *reinterpret_cast<f16x4_p*>(reinterpret_cast<_Float16*>(xn) + m * ldxn + c0) = h;
+                        } else {
                         typedef __bf16 bf16x4_p __attribute__((ext_vector_type(4)));
                         bf16x4_p h;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) h[e] = (__bf16)o[e];
                         *reinterpret_cast<bf16x4_p*>(reinterpret_cast<__bf16*>(xn) + m * ldxn + c0) = h;
+                        }
                     }
                 }
             }
@@ -160,7 +168,7 @@ bool patch_embed_ln_eligible(int Cin, int N, int k, int stride, int H, int W, in
 }
 hipError_t launch_patch_embed_ln(const float* img, int B, int H, int W, const float* wgt, int ldw, const float* bias, const float* gamma,
                                  const float* beta, float eps, float* x, int ldx, hipStream_t s, const float* gamma1, const float* beta1,
-                                 void* xn_bf16, int ldxn) {
+                                 void* xn_bf16, int ldxn, int xn_f16) {
     if (!patch_embed_ln_eligible(3, PE_N, 4, 4, H, W, ldw, ldx) || B <= 0 || !img || !wgt || !gamma || !beta || !x) return hipErrorInvalidValue;
     if (reinterpret_cast<uintptr_t>(x) & 15) return hipErrorInvalidValue;
     if (xn_bf16 && (!gamma1 || !beta1 || (ldxn & 3) || (reinterpret_cast<uintptr_t>(xn_bf16) & 7))) return hipErrorInvalidValue;
@@ -168,7 +176,7 @@ hipError_t launch_patch_embed_ln(const float* img, int B, int H, int W, const fl
     const long M = (long)B * (H >> 2) * (W >> 2);
     long tiles = (M + PE_TM - 1) / PE_TM;
     const int grid = (int)(tiles < 1024 ? tiles : 1024);
-    hipLaunchKernelGGL(patch_embed_ln_kernel, dim3(grid), dim3(256), 0, s, img, B, H, W, wgt, ldw, bias, gamma, beta, eps, x, ldx, img_aligned16, gamma1, beta1, xn_bf16, ldxn);
+    hipLaunchKernelGGL(patch_embed_ln_kernel, dim3(grid), dim3(256), 0, s, img, B, H, W, wgt, ldw, bias, gamma, beta, eps, x, ldx, img_aligned16, gamma1, beta1, xn_bf16, ldxn, xn_f16);
     return hipGetLastError();
 }
 

@@ -23,6 +23,7 @@
 #include "../brn_kernels.h"
 #include "split_planes.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace brn {
 
@@ -46,24 +47,26 @@ constexpr int ATT_THREADS = 192;   // 3 waves, 3 query tiles each
 // IOB = the qkv matrix and the output are bf16 (compute mode BRN_BF16 with a window the bf16 kernel below is not built for: window 7 of
 // Swin-T / S): operands are widened on load — a pad token's q / k / v is the qkv bias rounded to bf16, what the qkv GEMM of that mode would
 // have stored — the arithmetic stays the exact fp32 MFMA chain, the result is rounded once on store.
-template <bool IOB>
+template <int IOB>
 __device__ __forceinline__ f32x4 att_load4(const float* base, long off) {
-    if constexpr (IOB) {
-        typedef __bf16 bf16x4_ld __attribute__((ext_vector_type(4)));
-        const bf16x4_ld h = *reinterpret_cast<const bf16x4_ld*>(reinterpret_cast<const __bf16*>(base) + off);
+    if constexpr (IOB != 0) {                   // 1: bf16 matrices, 2: fp16 matrices (compute mode BRN_F16)
+        using E = std::conditional_t<IOB == 2, _Float16, __bf16>;
+        typedef E ex4_ld __attribute__((ext_vector_type(4)));
+        const ex4_ld h = *reinterpret_cast<const ex4_ld*>(reinterpret_cast<const E*>(base) + off);
         return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
     } else return *reinterpret_cast<const f32x4*>(base + off);
 }
-template <bool IOB>
+template <int IOB>
 __device__ __forceinline__ f32x4 att_bias4(const float* bias) {
     f32x4 v = *reinterpret_cast<const f32x4*>(bias);
-    if constexpr (IOB) {
+    if constexpr (IOB != 0) {
+        using E = std::conditional_t<IOB == 2, _Float16, __bf16>;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (float)(__bf16)v[e];
+        for (int e = 0; e < 4; ++e) v[e] = (float)(E)v[e];
     }
     return v;
 }
-template <int WSZ, int NWV = 3, bool IOB = false>
+template <int WSZ, int NWV = 3, int IOB = 0>
 __global__ void __launch_bounds__(NWV * 64) window_attention_f32_kernel(const WindowAttnParams pa, const WindowAttnParams pb, const int nblk0) {
     constexpr int WS = WSZ, NTOK = WSZ * WSZ, NT16 = (NTOK + 15) / 16, NPADTOK = NT16 * 16;
     constexpr int NTHR = NWV * 64;
@@ -228,14 +231,15 @@ __global__ void __launch_bounds__(NWV * 64) window_attention_f32_kernel(const Wi
                 float* orow = p.out + (long)qsrc * C;
                 store_planes_h(orow, head * HD + g * 4, o0 * inv, p.out_h2);
                 store_planes_h(orow, head * HD + 16 + g * 4, o1 * inv, p.out_h2);
-            } else if constexpr (IOB) {
-                typedef __bf16 bf16x4_st __attribute__((ext_vector_type(4)));
-                __bf16* op = reinterpret_cast<__bf16*>(p.out) + (long)qsrc * C + head * HD + g * 4;
-                bf16x4_st h0, h1;
+            } else if constexpr (IOB != 0) {
+                using E = std::conditional_t<IOB == 2, _Float16, __bf16>;
+                typedef E ex4_st __attribute__((ext_vector_type(4)));
+                E* op = reinterpret_cast<E*>(p.out) + (long)qsrc * C + head * HD + g * 4;
+                ex4_st h0, h1;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { h0[e] = (__bf16)(o0[e] * inv); h1[e] = (__bf16)(o1[e] * inv); }
-                *reinterpret_cast<bf16x4_st*>(op) = h0;
-                *reinterpret_cast<bf16x4_st*>(op + 16) = h1;
+                for (int e = 0; e < 4; ++e) { h0[e] = (E)(o0[e] * inv); h1[e] = (E)(o1[e] * inv); }
+                *reinterpret_cast<ex4_st*>(op) = h0;
+                *reinterpret_cast<ex4_st*>(op + 16) = h1;
             } else {
                 float* op = p.out + (long)qsrc * C + head * HD + g * 4;
                 *reinterpret_cast<f32x4*>(op) = o0 * inv;
@@ -532,23 +536,34 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-__device__ __forceinline__ bf16x8 bias8_bf16(const float* bp) {
-    bf16x8 r;
+template <typename E>
+__device__ __forceinline__ auto bias8_s16(const float* bp) {
+    typedef E ex8_b __attribute__((ext_vector_type(8)));
+    ex8_b r;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) r[e] = (__bf16)bp[e];
+    for (int e = 0; e < 8; ++e) r[e] = (E)bp[e];
     return r;
 }
 
 // Two heads per workgroup (6 waves: waves 0-2 head 2y, waves 3-5 head 2y + 1): a token's K (or V) rows of two adjacent heads are one
 // 128-byte line, so the staging loads fetch whole lines (one head per workgroup used half of every line it touched).
-template <int ATT_BF16_HPW>
+// F16: qkv / out are fp16 matrices (compute mode BRN_F16): the same kernel on v_mfma_f32_16x16x32_f16
+template <int ATT_BF16_HPW, bool F16 = false>
 __global__ void __launch_bounds__(ATT_BF16_HPW * ATT_THREADS) __attribute__((amdgpu_waves_per_eu(5, 8))) window_attention_bf16_kernel(const WindowAttnParams pa, const WindowAttnParams pb, const int nblk0) {
+    using E = std::conditional_t<F16, _Float16, __bf16>;
+    typedef E ex8 __attribute__((ext_vector_type(8)));
+    typedef E ex4 __attribute__((ext_vector_type(4)));
+    typedef E ex2 __attribute__((ext_vector_type(2)));
+    auto mfma = [](const ex8 a, const ex8 b, const f32x4 c) -> f32x4 {
+        if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    };
     const bool second = (int)blockIdx.x >= nblk0;
     const WindowAttnParams& p = second ? pb : pa;
     constexpr int TABN = (2 * WS - 1) * (2 * WS - 1);                 // 529
     constexpr float LOG2E = 1.4426950408889634f;
-    __shared__ __attribute__((aligned(16))) __bf16 Kp_[ATT_BF16_HPW][NTOK * HD];
-    __shared__ __attribute__((aligned(16))) __bf16 Vt_[ATT_BF16_HPW][HD * VT_LD];
+    __shared__ __attribute__((aligned(16))) E Kp_[ATT_BF16_HPW][NTOK * HD];
+    __shared__ __attribute__((aligned(16))) E Vt_[ATT_BF16_HPW][HD * VT_LD];
     // a head's bias table REVERSED and in log2 units: rev[j] = log2(e) * table[528 - j].  The 4 keys 16 kt + 4 g + {0..3} of a lane
     // lie in one window row (12 % 4 == 0), so their table entries are 4 consecutive words of rev: one index per key tile
     // instead of one per score (the index arithmetic was most of the softmax's VALU work).
@@ -563,12 +578,12 @@ __global__ void __launch_bounds__(ATT_BF16_HPW * ATT_THREADS) __attribute__((amd
     const int b = bw / nW, w = bw - b * nW;
     const int wr = w / nWw, wc = w - wr * nWw;
     const int C = p.C, C3 = 3 * C;
-    const __bf16* qkv = reinterpret_cast<const __bf16*>(p.qkv);
+    const E* qkv = reinterpret_cast<const E*>(p.qkv);
     const int li = lane & 15, g = lane >> 4;
     // the shift mask (swin.rs:283-296) is non-zero only in the last row / column of windows
     const bool has_mask = p.shift > 0 && (wr == nWh - 1 || wc == nWw - 1);
-    __bf16* Kp = Kp_[hp];
-    __bf16* Vt = Vt_[hp];
+    E* Kp = Kp_[hp];
+    E* Vt = Vt_[hp];
     const float* rev_s = rev_[hp];
 
     auto tok_src = [&](int t) {                                       // source row of window token t (roll + partition), -1 = pad token
@@ -586,13 +601,13 @@ __global__ void __launch_bounds__(ATT_BF16_HPW * ATT_THREADS) __attribute__((amd
     constexpr int NITEM = (NTOK / 2) * 4 * ATT_BF16_HPW;                // (token pair, head of the pair, 8-wide d chunk)
     constexpr int NTAB = ATT_BF16_HPW * TABN;
     static_assert(2 * NTHR >= NITEM && 3 * NTHR >= NTAB, "two staging items and three table words per thread cover a head group");
-    bf16x8 qf[3];
+    ex8 qf[3];
     int qsrc_[3];
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
         const int qs = tok_src((wv + 3 * u) * 16 + li);
         qsrc_[u] = qs;
-        qf[u] = *reinterpret_cast<const bf16x8*>(qkv + (long)max(qs, 0) * C3 + head * HD + g * 8);
+        qf[u] = *reinterpret_cast<const ex8*>(qkv + (long)max(qs, 0) * C3 + head * HD + g * 8);
     }
     float tbw[3];
 #pragma unroll
@@ -600,7 +615,7 @@ __global__ void __launch_bounds__(ATT_BF16_HPW * ATT_THREADS) __attribute__((amd
         const int i = min(tid + j * NTHR, NTAB - 1), hh = i / TABN, jj = i - hh * TABN;
         tbw[j] = p.rel_table[(blockIdx.y * ATT_BF16_HPW + hh) * TABN + (TABN - 1 - jj)];
     }
-    bf16x8 kv[2][2], vv[2][2];
+    ex8 kv[2][2], vv[2][2];
     int ssrc[2][2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -611,9 +626,9 @@ __global__ void __launch_bounds__(ATT_BF16_HPW * ATT_THREADS) __attribute__((amd
         for (int u = 0; u < 2; ++u) {
             const int src = tok_src(tp * 2 + u);
             ssrc[it][u] = src;
-            const __bf16* kp = qkv + (long)max(src, 0) * C3 + C + hd + c8;
-            kv[it][u] = *reinterpret_cast<const bf16x8*>(kp);
-            vv[it][u] = *reinterpret_cast<const bf16x8*>(kp + C);
+            const E* kp = qkv + (long)max(src, 0) * C3 + C + hd + c8;
+            kv[it][u] = *reinterpret_cast<const ex8*>(kp);
+            vv[it][u] = *reinterpret_cast<const ex8*>(kp + C);
         }
     }
     if (tid < NTOK) {
@@ -632,7 +647,7 @@ __global__ void __launch_bounds__(ATT_BF16_HPW * ATT_THREADS) __attribute__((amd
     }
 #pragma unroll
     for (int u = 0; u < 3; ++u)
-        if (qsrc_[u] < 0) qf[u] = bias8_bf16(p.qkv_bias + head * HD + g * 8);
+        if (qsrc_[u] < 0) qf[u] = bias8_s16<E>(p.qkv_bias + head * HD + g * 8);
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int idx = tid + it * NTHR;
@@ -642,29 +657,29 @@ __global__ void __launch_bounds__(ATT_BF16_HPW * ATT_THREADS) __attribute__((amd
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 if (ssrc[it][u] < 0) {
-                    kv[it][u] = bias8_bf16(p.qkv_bias + C + hd + c8);
-                    vv[it][u] = bias8_bf16(p.qkv_bias + 2 * C + hd + c8);
+                    kv[it][u] = bias8_s16<E>(p.qkv_bias + C + hd + c8);
+                    vv[it][u] = bias8_s16<E>(p.qkv_bias + 2 * C + hd + c8);
                 }
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int t = tp * 2 + u;
-                *reinterpret_cast<bf16x8*>(Kp_[hh] + t * HD + (((c8 >> 3) ^ kswz(t)) << 3)) = kv[it][u];
+                *reinterpret_cast<ex8*>(Kp_[hh] + t * HD + (((c8 >> 3) ^ kswz(t)) << 3)) = kv[it][u];
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                bf16x2 h;
+                ex2 h;
                 h[0] = vv[it][0][e]; h[1] = vv[it][1][e];
-                *reinterpret_cast<bf16x2*>(Vt_[hh] + (c8 + e) * VT_LD + tp * 2) = h;
+                *reinterpret_cast<ex2*>(Vt_[hh] + (c8 + e) * VT_LD + tp * 2) = h;
             }
         }
     }
     __syncthreads();
 
     const float scale2 = p.scale * LOG2E;
-    bf16x8 ones8;
+    ex8 ones8;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ones8[e] = (__bf16)1.0f;
+    for (int e = 0; e < 8; ++e) ones8[e] = (E)1.0f;
     // per key tile: koff = key0 + 11 (key0 / 12) for key0 = 16 kt + 4 g; the table word of (query, key0 + r) is rev[qrev + koff + r]
     // (byte offsets, one register per key tile, added to an LDS address the compiler cannot take apart: with `rev_s + qrev + koff[kt]`
     // it re-associated the array's constant base out of the sum and spent four VALU instructions per key tile on addresses: 94 of the
@@ -685,9 +700,9 @@ __global__ void __launch_bounds__(ATT_BF16_HPW * ATT_THREADS) __attribute__((amd
 #pragma unroll
         for (int kt = 0; kt < 9; ++kt) {
             const int key = kt * 16 + li;
-            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kp + key * HD + ((g ^ kswz(key)) << 3));
+            const ex8 kf = *reinterpret_cast<const ex8*>(Kp + key * HD + ((g ^ kswz(key)) << 3));
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[u], acc, 0, 0, 0);
+            st[kt] = mfma(kf, qf[u], acc);
             if (kt % 3 == 2) __builtin_amdgcn_sched_barrier(0);
         }
         float mx = -3.0e38f;
@@ -725,35 +740,35 @@ __global__ void __launch_bounds__(ATT_BF16_HPW * ATT_THREADS) __attribute__((amd
         f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f}, osum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 5; ++t) {
-            bf16x8 pf;
+            ex8 pf;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                pf[e] = (__bf16)st[2 * t][e];
-                pf[4 + e] = (2 * t + 1 < 9) ? (__bf16)st[(2 * t + 1 < 9) ? 2 * t + 1 : 0][e] : (__bf16)0.f;
+                pf[e] = (E)st[2 * t][e];
+                pf[4 + e] = (2 * t + 1 < 9) ? (E)st[(2 * t + 1 < 9) ? 2 * t + 1 : 0][e] : (E)0.f;
             }
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                const __bf16* vrow = Vt + (dt * 16 + li) * VT_LD + g * 4;
-                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow + (2 * t) * 16);
-                bf16x4 hi = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-                if (2 * t + 1 < 9) hi = *reinterpret_cast<const bf16x4*>(vrow + (2 * t + 1) * 16);
-                bf16x8 vf;
+                const E* vrow = Vt + (dt * 16 + li) * VT_LD + g * 4;
+                const ex4 lo = *reinterpret_cast<const ex4*>(vrow + (2 * t) * 16);
+                ex4 hi = {(E)0.f, (E)0.f, (E)0.f, (E)0.f};
+                if (2 * t + 1 < 9) hi = *reinterpret_cast<const ex4*>(vrow + (2 * t + 1) * 16);
+                ex8 vf;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
-                if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o0, 0, 0, 0);
-                else o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o1, 0, 0, 0);
+                if (dt == 0) o0 = mfma(vf, pf, o0);
+                else o1 = mfma(vf, pf, o1);
             }
-            osum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones8, pf, osum, 0, 0, 0);
+            osum = mfma(ones8, pf, osum);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (qsrc >= 0) {
             const float inv = __builtin_amdgcn_rcpf(osum[0]);
-            __bf16* op = reinterpret_cast<__bf16*>(p.out) + (long)qsrc * C + head * HD + g * 4;
-            bf16x4 h0, h1;
+            E* op = reinterpret_cast<E*>(p.out) + (long)qsrc * C + head * HD + g * 4;
+            ex4 h0, h1;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { h0[e] = (__bf16)(o0[e] * inv); h1[e] = (__bf16)(o1[e] * inv); }
-            *reinterpret_cast<bf16x4*>(op) = h0;
-            *reinterpret_cast<bf16x4*>(op + 16) = h1;
+            for (int e = 0; e < 4; ++e) { h0[e] = (E)(o0[e] * inv); h1[e] = (E)(o1[e] * inv); }
+            *reinterpret_cast<ex4*>(op) = h0;
+            *reinterpret_cast<ex4*>(op + 16) = h1;
         }
     }
 }
@@ -784,7 +799,8 @@ hipError_t launch_window_attention2(const WindowAttnParams& p, const WindowAttnP
     dim3 grid(n0 + n1, p.heads), block(ATT_THREADS);
     if (p.io_bf16 && ws == 7) {
         if (p.out_planes || (p.C & 3)) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((window_attention_f32_kernel<7, 3, true>), grid, block, 0, s, p, q, n0);
+        if (p.io_bf16 == 2) hipLaunchKernelGGL((window_attention_f32_kernel<7, 3, 2>), grid, block, 0, s, p, q, n0);
+        else hipLaunchKernelGGL((window_attention_f32_kernel<7, 3, 1>), grid, block, 0, s, p, q, n0);
     } else if (p.io_bf16) {
         if (p.out_planes || (p.C & 7)) return hipErrorInvalidValue;
         // (round 2, one stream: two heads per workgroup measured 1 % slower end to end, 224.5 vs 226.8 img/s at batch 8)
@@ -792,7 +808,10 @@ hipError_t launch_window_attention2(const WindowAttnParams& p, const WindowAttnP
         // whole 128-byte lines (one head per workgroup touches half of every line it fetches: 8.5 GB read against 5.9 algorithmic), and with
         // two sub-batch streams sharing the HBM the step is 1.0 % faster (tools/ab_env.sh BRN_ATT_HPW "1 2"); BRN_ATT_HPW=1 selects one head
         static const bool two_heads = !(getenv("BRN_ATT_HPW") && atoi(getenv("BRN_ATT_HPW")) == 1);
-        if (two_heads && !(p.heads & 1)) hipLaunchKernelGGL(window_attention_bf16_kernel<2>, dim3(n0 + n1, p.heads / 2), dim3(2 * ATT_THREADS), 0, s, p, q, n0);
+        if (p.io_bf16 == 2) {                  // fp16 matrices (compute mode BRN_F16)
+            if (two_heads && !(p.heads & 1)) hipLaunchKernelGGL((window_attention_bf16_kernel<2, true>), dim3(n0 + n1, p.heads / 2), dim3(2 * ATT_THREADS), 0, s, p, q, n0);
+            else hipLaunchKernelGGL((window_attention_bf16_kernel<1, true>), grid, block, 0, s, p, q, n0);
+        } else if (two_heads && !(p.heads & 1)) hipLaunchKernelGGL(window_attention_bf16_kernel<2>, dim3(n0 + n1, p.heads / 2), dim3(2 * ATT_THREADS), 0, s, p, q, n0);
         else hipLaunchKernelGGL(window_attention_bf16_kernel<1>, grid, block, 0, s, p, q, n0);
     } else if (p.planes == 2 && p.h2) hipLaunchKernelGGL((window_attention_split_kernel<2, true>), grid, block, 0, s, p, q, n0);
     else if (p.planes == 2) hipLaunchKernelGGL(window_attention_split_kernel<2>, grid, block, 0, s, p, q, n0);

@@ -3,7 +3,7 @@ Weights are host arrays; activations may be numpy (host) or torch-on-GPU (device
 from . import _ffi
 from . import tensors as T
 
-_COMPUTE = {"f32": _ffi.BRN_F32, "f32_split3": _ffi.BRN_F32_SPLIT3, "f32_split2": _ffi.BRN_F32_SPLIT2, "f32_half2": _ffi.BRN_F32_HALF2, "bf16": _ffi.BRN_BF16}
+_COMPUTE = {"f32": _ffi.BRN_F32, "f32_split3": _ffi.BRN_F32_SPLIT3, "f32_split2": _ffi.BRN_F32_SPLIT2, "f32_half2": _ffi.BRN_F32_HALF2, "bf16": _ffi.BRN_BF16, "f16": _ffi.BRN_F16}
 
 
 def set_compute(mode: str):

@@ -254,7 +254,7 @@ pub struct BiRefNet {
 
 impl BiRefNet {
     /// birefnet.rs:389 — same signature.  Compute mode and deform mode of the HIP backend come from the environment
-    /// (`BIREFNET_HIP_COMPUTE` = f32 | f32_split3 (default) | f32_split2 | f32_half2 | bf16 | bf16_dec_split2; `BIREFNET_HIP_DEFORM` =
+    /// (`BIREFNET_HIP_COMPUTE` = f32 | f32_split3 (default) | f32_split2 | f32_half2 | bf16 | f16 | bf16_dec_split2; `BIREFNET_HIP_DEFORM` =
     /// reference_cpu (default) | deformable) so that the reference's call sites compile unchanged.
     /// The HIP device and the largest batch the workspace is planned for come from `BIREFNET_HIP_DEVICE` (default 0) and
     /// `BIREFNET_HIP_MAX_BATCH` (default 1; larger batches re-plan on first use); `new_on` takes them as arguments.
@@ -356,6 +356,7 @@ fn compute_from_env() -> i32 {
         Ok("bf16") => ffi::BRN_BF16,
         Ok("bf16_dec_split2") => ffi::BRN_BF16_DEC_SPLIT2,
         Ok("f32_half2") => ffi::BRN_F32_HALF2,
+        Ok("f16") => ffi::BRN_F16,
         _ => ffi::BRN_F32_SPLIT3,
     }
 }

@@ -16,6 +16,7 @@ pub const BRN_BF16_OPERANDS: c_int = 3;
 pub const BRN_BF16: c_int = 4;
 pub const BRN_BF16_DEC_SPLIT2: c_int = 5;
 pub const BRN_F32_HALF2: c_int = 6;
+pub const BRN_F16: c_int = 7;
 /// brn_deform_mode
 pub const BRN_DEFORM_REFERENCE_CPU: c_int = 0;
 pub const BRN_DEFORM_DEFORMABLE: c_int = 1;

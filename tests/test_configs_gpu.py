@@ -15,10 +15,12 @@ ROOT = os.path.dirname(HERE)
 GOLD = os.path.join(HERE, "golden")
 # bf16 modes are throughput modes: the fp32 gate (1e-3 abs | 1e-2 rel) does not apply; their error against the fp64 / fp32
 # restatement is REPORTED and bounded here.  |logit| max of the 1024^2 synthetic run is ~2.2.
-BF16_ABS_BOUND = {"bf16": 2.4e-2}   # 3x the largest error measured on MI355X: 6.4e-3 (1024^2), 7.9e-3 (2048^2, deformable)
+BF16_ABS_BOUND = {"bf16": 2.4e-2,   # 3x the largest error measured on MI355X: 6.4e-3 (1024^2), 7.9e-3 (2048^2, deformable)
+                  "f16": 2.7e-3}    # compute mode f16 (fp16 storage), 3x the largest measured: 5.1e-4 (c3), 8.8e-4 (c3 deformable), 8.0e-4 (c5 deformable)
 # the same in mask space (forward() = sigmoid(logits), birefnet.rs:466-469; north_star: "masks within 1e-3 of reference" — an fp32
 # criterion): sigmoid' <= 1/4, so a logit error e is a mask error <= e / 4
 BF16_MASK_BOUND = 0.25 * BF16_ABS_BOUND["bf16"]
+S16_MASK_BOUND = {"bf16": BF16_MASK_BOUND, "f16": 1e-3}       # f16 (fp16 storage): under the north star's "masks within 1e-3"
 
 
 def _mask_err(m, x, gold_logits, stride):
@@ -34,7 +36,7 @@ def _full_model(mode, max_batch=0, size=0):
     return cb, cb.BiRefNet.new(cfg, cb.VarBuilder.from_tensors(w), compute=mode, max_batch=max_batch, max_size=(size, size))
 
 
-@pytest.mark.parametrize("mode", ["bf16"])
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
 def test_c3_batch8_1024_bf16(gpu, mode):
     """configs[2] (and one rank of configs[3]): B=8, 1024x1024.  Finite; the same call twice gives the same bits; an image alone
     equals the same image inside the batch up to the mode's rounding; error vs the strided fp64 golden of image 0 is bounded."""
@@ -52,7 +54,7 @@ def test_c3_batch8_1024_bf16(gpu, mode):
     d = max(float(np.abs(alone[0] - yn[0]).max()), float(np.abs(alone[1] - yn[5]).max()))
     em = _mask_err(m, x, k["m1024_full_ref_s16"][0], 16)
     print(f"c3 [{mode}] B=8 1024^2: max abs err of image 0 vs the fp64 golden {e0:.3e} (mask space {em:.3e}); image alone vs in batch {d:.3e}")
-    assert e0 < BF16_ABS_BOUND[mode] and d < BF16_ABS_BOUND[mode] and em < BF16_MASK_BOUND
+    assert e0 < BF16_ABS_BOUND[mode] and d < BF16_ABS_BOUND[mode] and em < S16_MASK_BOUND[mode]
     # the images of the batch are different images (seeds 1000..1007): a stuck batch index would show here
     assert float(np.abs(yn[1] - yn[0]).max()) > 0.1
     m.close()
@@ -84,11 +86,12 @@ def test_full_1024_deformable_fp32_equivalent_against_golden(gpu):
     m.close()
 
 
-def test_c3_batch8_1024_bf16_deformable(gpu):
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+def test_c3_batch8_1024_bf16_deformable(gpu, mode):
     """configs[2] / one rank of configs[3] in deform_mode=deformable (the bf16-MFMA gather kernel): B=8, 1024x1024, finite, repeatable,
     image 0 bounded against the fp64 golden, an image alone equals the image inside the batch up to the mode's rounding."""
     import torch
-    cb, m = _deform_model("bf16", 8, 1024)
+    cb, m = _deform_model(mode, 8, 1024)
     x = torch.from_numpy(cb.synth_input(8, 1024, 1024)).cuda()
     y = m.forward_logits(x)
     assert torch.isfinite(y).all() and torch.equal(y, m.forward_logits(x))
@@ -97,23 +100,24 @@ def test_c3_batch8_1024_bf16_deformable(gpu):
     e0 = float(np.abs(yn[0, :, ::16, ::16] - k["m1024_full_def_s16"][0]).max())
     d = float(np.abs(m.forward_logits(x[5:6]).cpu().numpy().astype(np.float64)[0] - yn[5]).max())
     em = _mask_err(m, x, k["m1024_full_def_s16"][0], 16)
-    print(f"c3 deformable [bf16] B=8 1024^2: max abs err of image 0 vs the fp64 golden {e0:.3e} (mask space {em:.3e}); image alone vs in batch {d:.3e}")
-    assert e0 < BF16_ABS_BOUND["bf16"] and d < BF16_ABS_BOUND["bf16"] and em < BF16_MASK_BOUND
+    print(f"c3 deformable [{mode}] B=8 1024^2: max abs err of image 0 vs the fp64 golden {e0:.3e} (mask space {em:.3e}); image alone vs in batch {d:.3e}")
+    assert e0 < BF16_ABS_BOUND[mode] and d < BF16_ABS_BOUND[mode] and em < S16_MASK_BOUND[mode]
     m.close()
 
 
-def test_c5_batch4_2048_bf16_deformable(gpu):
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+def test_c5_batch4_2048_bf16_deformable(gpu, mode):
     """configs[4] in deform_mode=deformable: B=4, 2048x2048 (dec1's ASPP gathers on 512^2 maps), against the fp32 restatement."""
     import torch
-    cb, m = _deform_model("bf16", 4, 2048)
+    cb, m = _deform_model(mode, 4, 2048)
     k = np.load(os.path.join(GOLD, "model_2048_def.npz"))
     x = torch.from_numpy(cb.synth_input(4, 2048, 2048)).cuda()
     y = m.forward_logits(x)
     assert torch.isfinite(y).all() and torch.equal(y, m.forward_logits(x))
     e0 = float(np.abs(y.cpu().numpy().astype(np.float64)[0, :, ::32, ::32] - k["m2048_full_def_s32"][0]).max())
     em = _mask_err(m, x, k["m2048_full_def_s32"][0], 32)
-    print(f"c5 deformable [bf16] B=4 2048^2: max abs err of image 0 vs the fp32 golden {e0:.3e} (mask space {em:.3e})")
-    assert e0 < BF16_ABS_BOUND["bf16"] and em < BF16_MASK_BOUND
+    print(f"c5 deformable [{mode}] B=4 2048^2: max abs err of image 0 vs the fp32 golden {e0:.3e} (mask space {em:.3e})")
+    assert e0 < BF16_ABS_BOUND[mode] and em < S16_MASK_BOUND[mode]
     m.close()
 
 

@@ -293,25 +293,30 @@ def test_split_conv_exact_and_repeatable(gpu, mode):
 ATT_BF16_TOL = 1.0e-2      # relative to max |ref|: 3x the largest measured on MI355X over _ATT_BF16_CASES (3.0e-3 .. 3.3e-3 of the scale)
 
 
-def _bf16_round(a):
-    """round-to-nearest-even fp32 -> bf16 -> fp32, as the library rounds operands (weights at load, activations at the edge)"""
-    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(torch.bfloat16).to(torch.float64).numpy()
+def _bf16_round(a, s16="bf16"):
+    """round-to-nearest-even fp32 -> bf16 (compute mode bf16) or fp16 (compute mode f16) -> fp32, as the library rounds operands (weights
+    at load, activations at the edge)"""
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(torch.float16 if s16 == "f16" else torch.bfloat16).to(torch.float64).numpy()
+
+
+S16_ULP = {"bf16": 2.0 ** -8, "f16": 2.0 ** -11}      # one unit in the last place of the mode's stored values, relative
 
 
 @pytest.mark.parametrize("M,K,N", [(300, 192, 576), (1000, 64, 512), (129, 768, 200), (64, 32, 16), (5000, 384, 1536), (7, 96, 130),
                                    (4096, 3072, 768), (513, 160, 64), (33000, 192, 192)])
 @pytest.mark.parametrize("act", [None, "gelu_erf"])
-def test_linear_bf16_mode(gpu, M, K, N, act):
+@pytest.mark.parametrize("s16", ["bf16", "f16"])
+def test_linear_bf16_mode(gpu, M, K, N, act, s16):
     """the linear entry keeps y and the residual fp32 in this mode, so the reference is EXACT up to fp32 accumulation order:
     operands rounded to bf16, products and sums in fp64.  K % 64 == 32 (the zero-page K tail), ragged M / N, split-K free."""
     from candle_birefnet_amd import ops
     x, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, std=K ** -0.5), rnd(N, seed=3), rnd(M, N, seed=4)
-    ops.set_compute("bf16")
+    ops.set_compute(s16)
     try:
         y = ops.linear(x, w, b, act=act, residual=r)
     finally:
         ops.set_compute("f32")
-    ref = torch.from_numpy(_bf16_round(x) @ _bf16_round(w).T) + torch.from_numpy(b).double()
+    ref = torch.from_numpy(_bf16_round(x, s16) @ _bf16_round(w, s16).T) + torch.from_numpy(b).double()
     if act == "gelu_erf":
         ref = F.gelu(ref)
     ref = ref + torch.from_numpy(r).double()
@@ -322,25 +327,27 @@ def test_linear_bf16_mode(gpu, M, K, N, act):
                                            (1, 64, 33, 17, 192, 3, 1), (2, 3456, 8, 8, 64, 3, 1), (1, 64, 24, 24, 16, 3, 1),
                                            (1, 128, 20, 20, 64, 3, 1), (2, 192, 15, 17, 192, 3, 1), (1, 960, 12, 12, 64, 3, 1), (1, 128, 13, 13, 256, 7, 3),
                                            (1, 1920, 16, 16, 64, 3, 1)])
-def test_conv2d_bf16_mode(gpu, B, C, H, W, O, k, p):
+@pytest.mark.parametrize("s16", ["bf16", "f16"])
+def test_conv2d_bf16_mode(gpu, B, C, H, W, O, k, p, s16):
     """implicit-GEMM conv on bf16 maps: zero padding through out-of-range buffer offsets (answered with zeros), Cin = 480 (K steps that straddle taps, K % 64 = 32),
     ragged maps, the tall-K split-K plan (3456 x 9), N = 16 (scalar stores); Cin = 128 / 192 / 960 / 1920 / 3456 run the chunk-major K
     order (64-channel chunk, tap, channel), 3x3 and 7x7, with and without split-K.  The output map is bf16: tolerance = one bf16 ulp."""
     from candle_birefnet_amd import ops
     x, w, b = rnd(B, C, H, W, seed=1), rnd(O, C, k, k, seed=2, std=(C * k * k) ** -0.5), rnd(O, seed=3, std=0.1)
-    ops.set_compute("bf16")
+    ops.set_compute(s16)
     try:
         y = ops.conv2d(x, w, b, padding=p, act="relu")
     finally:
         ops.set_compute("f32")
-    ref = F.relu(F.conv2d(torch.from_numpy(_bf16_round(x)), torch.from_numpy(_bf16_round(w)), torch.from_numpy(b).double(), padding=p)).numpy()
+    ref = F.relu(F.conv2d(torch.from_numpy(_bf16_round(x, s16)), torch.from_numpy(_bf16_round(w, s16)), torch.from_numpy(b).double(), padding=p)).numpy()
     err = np.abs(np.asarray(y, np.float64) - ref)
-    assert (err <= 2.0 ** -8 * np.abs(ref) + 1e-6).all(), f"max abs err {err.max():.3e}"
+    assert (err <= S16_ULP[s16] * np.abs(ref) + 1e-6).all(), f"max abs err {err.max():.3e}"
 
 
 @pytest.mark.parametrize("k,stride,pad,O,H,C", [(3, 1, 1, 128, 32, 64), (1, 1, 0, 256, 8, 64), (7, 1, 3, 256, 12, 64), (3, 2, 1, 64, 16, 64), (3, 1, 1, 256, 19, 128),
                                                 (1, 1, 0, 256, 40, 64), (7, 1, 3, 32, 9, 64)])
-def test_deform_conv2d_bf16_mode(gpu, k, stride, pad, O, H, C):
+@pytest.mark.parametrize("s16", ["bf16", "f16"])
+def test_deform_conv2d_bf16_mode(gpu, k, stride, pad, O, H, C, s16):
     """kernels/deform_bf16.hip (the bf16-MFMA gather of compute mode bf16) against an EXACT-operand reference: x and all three
     weights rounded to bf16, offsets / modulator / bilinear sampling / contraction in fp64 (the torchvision semantics of
     tests/torch_ref.py, aspp.rs:77-164).  What the kernel rounds on top: the sampled column (mask x bilinear) to bf16 before the MFMA,
@@ -356,29 +363,30 @@ def test_deform_conv2d_bf16_mode(gpu, k, stride, pad, O, H, C):
          "regular_conv.weight": rnd(O, C, k, k, seed=5, std=(C * k * k) ** -0.5), "regular_conv.bias": rnd(O, seed=6, std=0.1)}
     layer = cb.DeformableConv2d.new(C, O, k, stride, pad, cb.VarBuilder.from_tensors(t), mode="deformable")
     x = rnd(2, C, H, H, seed=9)
-    ops.set_compute("bf16")
+    ops.set_compute(s16)
     try:
         y = layer.forward(x)
         y2 = layer.forward(x)
     finally:
         ops.set_compute("f32")
     np.testing.assert_array_equal(y, y2)
-    xt = torch.from_numpy(_bf16_round(x))
-    td = {n: torch.from_numpy(_bf16_round(a) if n.endswith("weight") else np.asarray(a, np.float64)) for n, a in t.items()}
+    xt = torch.from_numpy(_bf16_round(x, s16))
+    td = {n: torch.from_numpy(_bf16_round(a, s16) if n.endswith("weight") else np.asarray(a, np.float64)) for n, a in t.items()}
     off = F.conv2d(xt, td["offset_conv.weight"], td["offset_conv.bias"], stride=stride, padding=pad)
     msk = 1.0 / (torch.exp(-F.conv2d(xt, td["modulator_conv.weight"], td["modulator_conv.bias"], stride=stride, padding=pad)) + 1.0) * 2.0
     ref = R.deform_conv2d(xt, off, msk, td["regular_conv.weight"], td["regular_conv.bias"], stride, pad).numpy()
     err = np.abs(np.asarray(y, np.float64) - ref)
     # sampled columns carry <= 2^-9 relative rounding each (independent over K = C k^2 terms), the output one bf16 rounding
     scale = np.abs(ref).max()
-    assert (err <= 2.0 ** -8 * np.abs(ref) + 4e-3 * scale).all(), f"max abs err {err.max():.3e} (|ref| max {scale:.2f})"
-    print(f"deform bf16 k{k} s{stride} O{O} H{H} C{C}: max abs err {err.max():.2e}, |ref| max {scale:.2f}")
+    # (compute mode f16, fp16 storage: the same kernel in namespace brn::hf, every bound 8 x tighter)
+    assert (err <= S16_ULP[s16] * np.abs(ref) + (4e-3 if s16 == "bf16" else 5e-4) * scale).all(), f"max abs err {err.max():.3e} (|ref| max {scale:.2f})"
+    print(f"deform {s16} k{k} s{stride} O{O} H{H} C{C}: max abs err {err.max():.2e}, |ref| max {scale:.2f}")
 
 
 _ATT_BF16_CASES = [(1, 12, 12, 2, 0), (2, 24, 24, 3, 6), (1, 16, 16, 2, 6), (1, 16, 16, 2, 0), (1, 32, 20, 6, 6), (1, 4, 4, 1, 6), (1, 64, 64, 24, 6), (2, 36, 36, 12, 6)]
 
 
-def _att_bf16_reference(B, H, W, heads, shift, qk_gain=1.0):
+def _att_bf16_reference(B, H, W, heads, shift, qk_gain=1.0, s16="bf16"):
     """exact-operand reference of window_attention_bf16_kernel between its two GEMMs: x and the weights rounded to bf16, the qkv
     matrix and the attention output rounded to bf16 where the mode stores them in HBM, everything else (scores, bias, mask, softmax,
     PV, proj) in fp64.  What the kernel adds: fp32 accumulation, softmax numerators rounded to bf16 for the PV MFMA, exp2 on
@@ -389,20 +397,21 @@ def _att_bf16_reference(B, H, W, heads, shift, qk_gain=1.0):
         w["attn.qkv.weight"] = w["attn.qkv.weight"].copy(); w["attn.qkv.bias"] = w["attn.qkv.bias"].copy()
         w["attn.qkv.weight"][:2 * C] *= np.float32(qk_gain); w["attn.qkv.bias"][:2 * C] *= np.float32(qk_gain)
     x = rnd(B, H, W, C, seed=99)
-    wr = {n: (_bf16_round(a) if n in ("attn.qkv.weight", "attn.proj.weight") else np.asarray(a, np.float64)) for n, a in w.items()}
-    store = lambda t: t.to(torch.bfloat16).to(torch.float64)
-    ref = R.window_attention_block(torch.from_numpy(_bf16_round(x)), wr, "", heads, 12, shift, torch.float64, store=store).numpy()
+    wr = {n: (_bf16_round(a, s16) if n in ("attn.qkv.weight", "attn.proj.weight") else np.asarray(a, np.float64)) for n, a in w.items()}
+    store = lambda t: t.to(torch.float16 if s16 == "f16" else torch.bfloat16).to(torch.float64)
+    ref = R.window_attention_block(torch.from_numpy(_bf16_round(x, s16)), wr, "", heads, 12, shift, torch.float64, store=store).numpy()
     return x, w, ref
 
 
 @pytest.mark.parametrize("B,H,W,heads,shift", _ATT_BF16_CASES)
-def test_window_attention_bf16_mode(gpu, B, H, W, heads, shift):
+@pytest.mark.parametrize("s16", ["bf16", "f16"])
+def test_window_attention_bf16_mode(gpu, B, H, W, heads, shift, s16):
     """op-level parity of window_attention_bf16_kernel (compute mode bf16; swin.rs:266-312 on bf16 qkv): one window, 4 windows with the
     shift mask, R = 16 padded to 24 (pad tokens synthesised from the qkv bias, shifted and not), a ragged map, tiny maps, the stage-2
     head count (24) and the stage-1 geometry (36 = 3 windows a side)."""
     from candle_birefnet_amd import ops
-    x, w, ref = _att_bf16_reference(B, H, W, heads, shift)
-    ops.set_compute("bf16")
+    x, w, ref = _att_bf16_reference(B, H, W, heads, shift, s16=s16)
+    ops.set_compute(s16)
     try:
         y = ops.window_attention(x, heads, shift, w["attn.qkv.weight"], w["attn.qkv.bias"], w["attn.proj.weight"], w["attn.proj.bias"],
                                  w["attn.relative_position_bias_table"])
@@ -413,8 +422,8 @@ def test_window_attention_bf16_mode(gpu, B, H, W, heads, shift):
     np.testing.assert_array_equal(y, y2)
     err = np.abs(np.asarray(y, np.float64) - ref)
     scale = np.abs(ref).max()
-    print(f"attention bf16 B{B} {H}x{W} h{heads} s{shift}: max abs err {err.max():.2e}, |ref| max {scale:.2f}")
-    assert err.max() <= ATT_BF16_TOL * scale
+    print(f"attention {s16} B{B} {H}x{W} h{heads} s{shift}: max abs err {err.max():.2e}, |ref| max {scale:.2f}")
+    assert err.max() <= ATT_BF16_TOL * scale * (1.0 if s16 == "bf16" else 0.125)
 
 
 @pytest.mark.parametrize("B,H,W,heads", [(2, 24, 24, 2), (1, 32, 20, 6), (1, 36, 36, 4)])

@@ -82,7 +82,7 @@ def test_window_attention_window7(gpu, H, W, shift):
 
 
 @pytest.mark.parametrize("name,depths,B,H,W", [("swin_t", [2, 2, 2, 2], 1, 250, 203), ("swin_s", [2, 2, 4, 2], 2, 224, 224), ("swin_b", [2, 2, 2, 2], 1, 131, 90)])
-@pytest.mark.parametrize("compute", ["f32_split3", "f32_split2", "f32_half2", "bf16"])
+@pytest.mark.parametrize("compute", ["f32_split3", "f32_split2", "f32_half2", "bf16", "f16"])
 def test_swin_configs_in_every_compute_mode(gpu, name, depths, B, H, W, compute):
     """VERDICT r3 missing #3: the stand-alone SwinTransformer in the split and bf16 modes, window 7 included (Swin-T / S: the fp32-MFMA
     attention kernel on the mode's matrices — bf16 in / out in mode bf16 — between the mode's own GEMMs).  Against the CPU oracle: the
@@ -104,4 +104,4 @@ def test_swin_configs_in_every_compute_mode(gpu, name, depths, B, H, W, compute)
         np.testing.assert_array_equal(a, a2)
         err = float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())
         scale = max(1.0, float(np.abs(b).max()))
-        assert err <= (3e-2 if compute == "bf16" else 3e-4) * scale, f"{name} {compute}: max abs err {err:.3e} (scale {scale:.2f})"
+        assert err <= {"bf16": 3e-2, "f16": 4e-3}.get(compute, 3e-4) * scale, f"{name} {compute}: max abs err {err:.3e} (scale {scale:.2f})"

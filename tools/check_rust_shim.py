@@ -92,7 +92,7 @@ def main():
     for name in rf:
         if name not in hf:
             errs.append(f"{name}: in hip_ffi.rs but not in the header")
-    for const, enum_pat in (("BRN_F32", 0), ("BRN_F32_SPLIT3", 1), ("BRN_F32_SPLIT2", 2), ("BRN_BF16_OPERANDS", 3), ("BRN_BF16", 4), ("BRN_BF16_DEC_SPLIT2", 5), ("BRN_F32_HALF2", 6),
+    for const, enum_pat in (("BRN_F32", 0), ("BRN_F32_SPLIT3", 1), ("BRN_F32_SPLIT2", 2), ("BRN_BF16_OPERANDS", 3), ("BRN_BF16", 4), ("BRN_BF16_DEC_SPLIT2", 5), ("BRN_F32_HALF2", 6), ("BRN_F16", 7),
                             ("BRN_MEM_HOST", 0), ("BRN_MEM_DEVICE", 1), ("BRN_DEFORM_REFERENCE_CPU", 0), ("BRN_DEFORM_DEFORMABLE", 1)):
         hm = re.search(r"\b%s = (\d+)" % const, h)
         rm = re.search(r"pub const %s: c_int = (\d+);" % const, r)
