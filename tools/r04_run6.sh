@@ -7,5 +7,5 @@ for args in "c3 bf16 r04" "c3 bf16 r04 deformable" "c2 f32_half2 r04" "c2 f32_sp
   timeout -k 10 300 bash tools/profile_config.sh $args > $L 2>&1 || { echo "profile $args failed"; tail -5 $L; exit 1; }
   tail -1 $L
 done
-timeout -k 10 400 python bench.py > gpurun_out/r04_bench_default.json 2> gpurun_out/r04_bench_default.err || { tail -5 gpurun_out/r04_bench_default.err; exit 1; }
+timeout -k 10 800 python bench.py > gpurun_out/r04_bench_default.json 2> gpurun_out/r04_bench_default.err || { tail -5 gpurun_out/r04_bench_default.err; exit 1; }
 python -c "import json; d=json.load(open('gpurun_out/r04_bench_default.json')); print(json.dumps(d['summary']))"
