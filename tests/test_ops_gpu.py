@@ -508,7 +508,7 @@ def test_conv2d_nan_stays_local(gpu):
     from candle_birefnet_amd import ops
     x, w = rnd(1, 64, 12, 12, seed=1), rnd(32, 64, 3, 3, seed=2, std=0.05)
     x[0, 3, 0, 0] = np.inf
-    for mode in ("f32", "f32_split3", "f32_split2", "bf16"):
+    for mode in ("f32", "f32_split3", "f32_split2", "f32_half2", "bf16", "f16"):
         ops.set_compute(mode)
         try:
             y = np.asarray(ops.conv2d(x, w, None, padding=1))
@@ -670,7 +670,7 @@ def test_linear_residual_layer_norm_fp32_modes(gpu):
     xr = a.astype(np.float64) @ w.astype(np.float64).T + b + r
     mu = xr.mean(-1, keepdims=True)
     yr = (xr - mu) / np.sqrt(((xr - mu) ** 2).mean(-1, keepdims=True) + 1e-5) * g + bt
-    for mode in ("f32", "f32_split3", "f32_split2"):
+    for mode in ("f32", "f32_split3", "f32_split2", "f32_half2"):
         ops.set_compute(mode)
         try:
             xo, yo = ops.linear_residual_layer_norm(a, w, b, r, g, bt)

@@ -8,7 +8,7 @@ import torch_ref as R
 import test_ops_gpu as T
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-TOL = {"f32": 2e-5, "f32_split3": 2e-5, "f32_split2": 1e-4}
+TOL = {"f32": 2e-5, "f32_split3": 2e-5, "f32_half2": 2e-5, "f32_split2": 1e-4, "f16": 3.2e-3}
 bad = 0
 for it in range(n):
     B = int(rng.integers(1, 4)); H = int(rng.integers(1, 50)); W = int(rng.integers(1, 50)); heads = int(rng.choice([1, 2, 3, 6, 12, 24])); shift = int(rng.choice([0, 6]))
@@ -17,7 +17,7 @@ for it in range(n):
     w = T._attn_weights(C, heads, seed=10 + it)
     x = T.rnd(B, H, W, C, seed=99 + it)
     ref = R.window_attention_block(torch.from_numpy(x).double(), w, "", heads, 12, shift, torch.float64).numpy()
-    for mode in ("f32", "f32_split3", "f32_split2", "bf16"):
+    for mode in ("f32", "f32_split3", "f32_half2", "f32_split2", "bf16", "f16"):
         ops.set_compute(mode)
         try:
             y = np.asarray(ops.window_attention(x, heads, shift, w["attn.qkv.weight"], w["attn.qkv.bias"], w["attn.proj.weight"], w["attn.proj.bias"],

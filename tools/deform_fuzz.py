@@ -9,7 +9,7 @@ from candle_birefnet_amd import ops
 import torch_ref as R
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-TOL = {"f32": 2e-4, "f32_split3": 2e-4, "f32_split2": 5e-4, "bf16": 3e-2}
+TOL = {"f32": 2e-4, "f32_split3": 2e-4, "f32_half2": 2e-4, "f32_split2": 5e-4, "bf16": 3e-2, "f16": 4e-3}
 bad = 0
 for it in range(n):
     C = int(rng.choice([32, 64, 96, 128])); O = int(rng.choice([8, 32, 64, 100, 128, 256])); k = int(rng.choice([1, 3, 3, 7])); s = int(rng.choice([1, 1, 2]))
@@ -31,7 +31,7 @@ for it in range(n):
         ref = ref.numpy()
         layer = cb.DeformableConv2d.new(C, O, k, s, pad, cb.VarBuilder.from_tensors(t), mode=dm)
         desc = f"{dm} B{B} C{C} O{O} k{k} s{s} p{pad} {H}x{W}"
-        for mode in ("f32", "f32_split3", "f32_split2", "bf16"):
+        for mode in ("f32", "f32_split3", "f32_half2", "f32_split2", "bf16", "f16"):
             ops.set_compute(mode)
             try:
                 y = np.asarray(layer.forward(x), np.float64)

@@ -6,8 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from candle_birefnet_amd import ops
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-def r16(a): return torch.from_numpy(a).to(torch.bfloat16).to(torch.float64)
-TOL = {"f32": 2e-5, "f32_split3": 2e-5, "f32_split2": 2e-4, "bf16": 1.2e-2}
+def r16(a, mode="bf16"): return torch.from_numpy(a).to(torch.float16 if mode == "f16" else torch.bfloat16).to(torch.float64)
+TOL = {"f32": 2e-5, "f32_split3": 2e-5, "f32_half2": 2e-5, "f32_split2": 2e-4, "bf16": 1.2e-2, "f16": 1.5e-3}
 bad = 0
 for it in range(n):
     kind = "conv" if rng.random() < 0.7 else "linear"
@@ -27,16 +27,16 @@ for it in range(n):
         b = rng.standard_normal(N, dtype=np.float32) * 0.1 if rng.random() < 0.7 else None
         res = rng.standard_normal((M, N), dtype=np.float32) if rng.random() < 0.4 else None
         desc = f"linear M{M} K{K} N{N} act={act} bias={b is not None} res={res is not None}"
-    for mode in ("f32", "f32_split3", "f32_split2", "bf16"):
+    for mode in ("f32", "f32_split3", "f32_half2", "f32_split2", "bf16", "f16"):
         ops.set_compute(mode)
         try:
             if kind == "conv":
                 y = np.asarray(ops.conv2d(x, w, b, stride=s, padding=pad, dilation=dil, act=act), np.float64)
-                xr, wr = (r16(x), r16(w)) if mode == "bf16" else (torch.from_numpy(x).double(), torch.from_numpy(w).double())
+                xr, wr = (r16(x, mode), r16(w, mode)) if mode in ("bf16", "f16") else (torch.from_numpy(x).double(), torch.from_numpy(w).double())
                 ref = F.conv2d(xr, wr, None if b is None else torch.from_numpy(b).double(), stride=s, padding=pad, dilation=dil)
             else:
                 y = np.asarray(ops.linear(x, w, b, act=act, residual=res), np.float64)
-                xr, wr = (r16(x), r16(w)) if mode == "bf16" else (torch.from_numpy(x).double(), torch.from_numpy(w).double())
+                xr, wr = (r16(x, mode), r16(w, mode)) if mode in ("bf16", "f16") else (torch.from_numpy(x).double(), torch.from_numpy(w).double())
                 ref = xr @ wr.T + (0 if b is None else torch.from_numpy(b).double())
             ref = F.gelu(ref) if act == "gelu_erf" else F.relu(ref) if act == "relu" else ref
             if kind == "linear" and res is not None: ref = ref + torch.from_numpy(res).double()
