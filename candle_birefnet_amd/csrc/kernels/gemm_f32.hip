@@ -698,7 +698,16 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
     constexpr int AQ = KS / 4, RPP = 256 / AQ;                  // producers: 256 threads, AQ float4 per KS-float row
     constexpr int PA = APL ? 2 * NP : BM / RPP;                 // P-layout input: 4 NP 16-byte chunks per (row, K tile), 128 rows / 256 threads
     constexpr int WQ = KS / 8, WRPP = 256 / WQ, PB = BN / WRPP; // WQ 16-byte chunks per KS-bf16 row
-    constexpr int BUF = NP * (BM + BN) * SLD;       // bf16 elements per LDS buffer
+    // P-layout input: ONE ds_write_b128 instruction covers both planes of a row (lanes c = 0..3 plane 0, 4..7 plane 1), and BM x SLD x 2 bytes is a
+    // multiple of the 256-byte bank row: the two planes of a row would sit on the same banks (2-way conflict on every staging write: 2.5 % of
+    // wave cycles in profiles/r04_pmc_sq_c2_f32_half2.csv).  Plane p of A is therefore shifted by p x 128 bytes: rows r, r + 1 of both planes then
+    // cover the four 64-byte quarters of a bank row.  (The fragment reads stay conflict-free: a constant shift per plane.)
+#ifndef BRN_APL_PAD
+#define BRN_APL_PAD 1
+#endif
+    constexpr int APAD = (BRN_APL_PAD && APL && KS == 32) ? 64 : 0;            // elements (BRN_APL_PAD=0 builds the unshifted layout: tools/ab_lib.sh)
+    constexpr int AREG = NP * BM * SLD + (NP - 1) * APAD;       // A region of a buffer
+    constexpr int BUF = AREG + NP * BN * SLD;       // bf16 elements per LDS buffer
     constexpr int EP_LD = BN + 4;                   // floats per row of the epilogue's LDS image of the C tile
     constexpr int SMEM_MAIN = NBUF * BUF * 2, SMEM_EPI = BM * EP_LD * 4;   // bytes
     __shared__ __attribute__((aligned(16))) char smem_raw[SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI];
@@ -749,7 +758,7 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
             if (APL) {
                 const int q = i * 256 + pt, row = q / (4 * NP), c = q - row * (4 * NP);   // chunk c of the row: plane c / 4, k = 8 (c % 4)
                 m = m0 + row;
-                p_lds[i] = ((c >> 2) * BM + row) * SLD + ((c & 3) ^ swz_key(row)) * 8;
+                p_lds[i] = ((c >> 2) * BM + row) * SLD + (c >> 2) * APAD + ((c & 3) ^ swz_key(row)) * 8;
             }
             a_ok[i] = m < p.M;
             a_iy[i] = 0; a_ix[i] = 0;
@@ -884,7 +893,7 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
         };
         auto lds_store = [&](int t, const f32x4 (&qa)[PA], const bf16x8 (&qb)[NP][PB], const unsigned (&qm)[PA]) {
             __bf16* As = smem + (t % NBUF) * BUF;
-            __bf16* Bs = As + NP * BM * SLD;
+            __bf16* Bs = As + AREG;
             if (APL) {
                 // 16 bytes = 8 bf16 of plane kq >> 2 at k = 8 (kq & 3): one ds_write_b128, no arithmetic (rows beyond M were
                 // loaded from row 0 and are zeroed by an integer AND with the row's 0 / ~0 mask)
@@ -953,7 +962,7 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
     const int wm = wave >> 1, wn = wave & 1;
     // (the swizzle key of a fragment row depends on its low five bits only: every block offset below is a multiple of 32 rows)
     const int fkey = swz_key(lane & 31);
-    const int a_row = (wm * WTM + (lane & 31)) * SLD, b_row = NP * BM * SLD + (wn * WTN + (lane & 31)) * SLD;
+    const int a_row = (wm * WTM + (lane & 31)) * SLD, b_row = AREG + (wn * WTN + (lane & 31)) * SLD;
     int f_chunk[KSTEPS];
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) f_chunk[ks] = (((lane >> 5) + 2 * ks) ^ fkey) * 8;
@@ -962,7 +971,7 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[pl][i] = *reinterpret_cast<const bf16x8*>(buf + a_row + (pl * BM + i * 32) * SLD + f_chunk[ks]);
+            for (int i = 0; i < TM; ++i) af[pl][i] = *reinterpret_cast<const bf16x8*>(buf + a_row + (pl * BM + i * 32) * SLD + pl * APAD + f_chunk[ks]);
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[pl][j] = *reinterpret_cast<const bf16x8*>(buf + b_row + (pl * BN + j * 32) * SLD + f_chunk[ks]);
         }
