@@ -344,7 +344,7 @@ const char* brn_last_error(void) { return last_error_cstr(); }
 const char* brn_build_info(void) {
 #define BRN_STR2(x) #x
 #define BRN_STR(x) BRN_STR2(x)
-    return "libbirefnet_hip gfx950 (CDNA4): compute modes f32 (fp32 MFMA), f32_split3 / f32_split2 (split-bf16 MFMA, fp32 storage), f32_half2 (fp16-pair MFMA, fp32 storage), bf16 (bf16 storage + MFMA); HIP " BRN_STR(HIP_VERSION_MAJOR) "." BRN_STR(HIP_VERSION_MINOR) "." BRN_STR(HIP_VERSION_PATCH);
+    return "libbirefnet_hip gfx950 (CDNA4): compute modes f32 (fp32 MFMA), f32_split3 / f32_split2 (split-bf16 MFMA, fp32 storage), f32_half2 (fp16-pair MFMA, fp32 storage), bf16 / f16 (bf16 / fp16 storage + MFMA); HIP " BRN_STR(HIP_VERSION_MAJOR) "." BRN_STR(HIP_VERSION_MINOR) "." BRN_STR(HIP_VERSION_PATCH);
 }
 brn_status brn_device_count(int* n) {
     return guarded([&] {
