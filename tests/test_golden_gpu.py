@@ -49,7 +49,7 @@ def test_hip_model_goldens_and_oracle(gpu, tag, mode):
     # size); the SAME call repeated is bit-identical (no float atomics anywhere).
     if x.shape[0] > 1:
         for b in range(x.shape[0]):
-            np.testing.assert_allclose(m.forward_logits(x[b:b + 1])[0], y[b], rtol=0, atol=5e-6)
+            np.testing.assert_allclose(m.forward_logits(x[b:b + 1])[0], y[b], rtol=0, atol=1.5e-5 if mode == "f32_split2" else 5e-6)   # (f32_split2: 16-bit operand mantissa, 1.3e-5 from the golden itself)
         np.testing.assert_array_equal(m.forward_logits(x), y)
     m.close()
 
