@@ -111,7 +111,7 @@ def parse_args(argv=None):
     ap.add_argument("--compute", default="", choices=[""] + list(MODES),
                     help="arithmetic of the contraction kernels (include/birefnet_hip.h brn_dtype; overrides --config)")
     ap.add_argument("--strong", action="store_true", help="strong scaling: the config's 8-GPU global batch (images/GPU x 8) is split over the ranks")
-    ap.add_argument("--also", default=None, help="comma list of other compute modes to time briefly on rank 0 at N=1 ('' = none; default: f32_split3,f32_split2,f32 for c2)")
+    ap.add_argument("--also", default=None, help="comma list of other compute modes to time briefly on rank 0 at N=1 ('' = none; default: f32_split3,f32_split2,f32,f16 for c2)")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra steps with per-launch HIP events for the roofline block")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off", "on"])
     ap.add_argument("--other-configs", default="auto", choices=["auto", "off", "on"],
@@ -311,7 +311,7 @@ def main(argv=None):
         B, scaling = gb // world, "strong"
     custom = (B, S, compute) != (cB, cS, cmode) and not args.strong
     default_line = args.config == "c2" and not custom and not args.strong and args.deform_mode == "reference_cpu"
-    also = args.also if args.also is not None else ("f32_split3,f32_split2,f32" if (args.config == "c2" and not custom) else "")
+    also = args.also if args.also is not None else ("f32_split3,f32_split2,f32,f16" if (args.config == "c2" and not custom) else "")
     others_on = args.other_configs == "on" or (args.other_configs == "auto" and default_line)
 
     import numpy as np
@@ -461,7 +461,9 @@ def main(argv=None):
             dtm = (time.perf_counter() - t0m) / 5
             others[mode] = {"images_per_s": round(B / dtm, 3), "ms_per_step": round(dtm * 1e3, 3), "dtype": MODES[mode][1]}
             if ref_np is not None:
-                others[mode]["gpu_vs_oracle_max_abs_err"] = float(np.abs(y2[:1].float().cpu().numpy().astype(np.float64) - ref_np).max())
+                e2 = np.abs(y2[:1].float().cpu().numpy().astype(np.float64) - ref_np)
+                others[mode]["gpu_vs_oracle_max_abs_err"] = float(e2.max())
+                others[mode]["gpu_vs_oracle_gate_1e-3abs_or_1e-2rel"] = bool(((e2 <= 1e-3) | (e2 <= 1e-2 * np.abs(ref_np))).all())
             m2.close()
     gold_headline = golden_error(y, S, args.deform_mode) if (rank == 0 and not custom) else None
     # mask space: forward() = sigmoid(logits) (birefnet.rs:466-469) of image 0 against sigmoid(golden logits)
