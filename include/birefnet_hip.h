@@ -43,7 +43,7 @@ enum {
 };
 
 typedef enum { BRN_MEM_HOST = 0, BRN_MEM_DEVICE = 1 } brn_mem;
-/* Arithmetic of the contraction kernels.  In the first four modes everything else — LayerNorm, softmax, epilogues,
+/* Arithmetic of the contraction kernels.  In the BRN_F32* modes (and BRN_BF16_OPERANDS) everything else — LayerNorm, softmax, epilogues,
  * storage — is fp32 (the reference runs DType::F32, infer_image.rs:26):
  *   BRN_F32            fp32 operands on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32), exact fmaf chain
  *   BRN_F32_SPLIT3     fp32 operands split error-free into 3 bf16 planes, 6 bf16 MFMAs per product, fp32 accumulate:
