@@ -675,6 +675,9 @@ template <int MODE, int NP, int KS, bool DIAG, bool APL, bool H = false>   // AP
 // H: the two planes are fp16 planes of the scaled operands (mode f32_half2; split4h / v_mfma_f32_32x32x16_f16), same bytes and layouts
 // DIAG: ablation switches + per-K-tile cycle stamps (brn_gemm_microbench only; costs registers)
 // KS = k elements per LDS stage (32, or 16 to halve the stage when 3 planes must fit twice per CU)
+#ifndef BRN_WS_M16
+#define BRN_WS_M16 1          // 2-plane, 32-deep stages: the consumers issue 16 x 16 x 32 MFMAs (0: 32 x 32 x 16, same-box A/B builds)
+#endif
 __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) {
     constexpr int BM = 128, BN = 128, WTM = 64, WTN = 64, TM = 2, TN = 2;
     static_assert(!APL || ((NP == 2 || NP == 3) && MODE == GEMM_DENSE), "the P input layout is the NP-plane split of a dense A");
@@ -951,6 +954,72 @@ __global__ void __launch_bounds__(512) gemm_split_ws_kernel(const GemmParams p) 
         }
 #undef BRN_PROD_STEP
         if (trc && tid == 256) { trc[8 + 4] = clock64(); trc[8 + 5] = wall_clock64(); }
+    } else if constexpr (BRN_WS_M16 != 0 && KS == 32 && NP == 2 && !DIAG) {
+    // ---- consumers, 16 x 16 x 32 MFMAs (round 4): the same cycles per flop as 32 x 32 x 16, but the chip holds a higher clock under the smaller
+    // shape (MI355X_MICROARCH.md, DVFS; gemm_bf16.hip measured + 5 ... 13 % on its LDS-fed tiles).  One MFMA k = the whole 32-deep stage; a wave's
+    // 64 x 64 is 4 x 4 blocks, multiplied as four 2 x 2 quadrants.  Fragment of a 16-row block: lane l reads row l & 15, 16-byte k chunk l >> 4 (XOR the row's key).
+    f32x4 acc4[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc4[i][j] = zero4();
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r16 = lane & 15, kc = lane >> 4;
+    const int fch = (kc ^ swz_key(r16)) * 8;           // (the key of a row depends on its bits 2, 3: the same in every 16-row block)
+    const int a_row = (wm * WTM + r16) * SLD + fch, b_row = AREG + (wn * WTN + r16) * SLD + fch;
+    auto read_a = [&](int t, int half, bf16x8 (&af)[NP][2]) {
+        const __bf16* buf = smem + (t % NBUF) * BUF;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[pl][i] = *reinterpret_cast<const bf16x8*>(buf + a_row + (pl * BM + (half * 2 + i) * 16) * SLD + pl * APAD);
+    };
+    auto read_b = [&](int t, int half, bf16x8 (&bf)[NP][2]) {
+        const __bf16* buf = smem + (t % NBUF) * BUF;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[pl][j] = *reinterpret_cast<const bf16x8*>(buf + b_row + (pl * BN + (half * 2 + j) * 16) * SLD);
+    };
+    auto mfma_quad = [&](const bf16x8 (&af)[NP][2], const bf16x8 (&bf)[NP][2], const int ih, const int jh) {
+#pragma unroll
+        for (int sum = NP - 1; sum >= 0; --sum)        // smallest plane products first
+#pragma unroll
+            for (int pa = 0; pa < NP; ++pa) {
+                const int pb = sum - pa;
+                if (pb < 0 || pb >= NP) continue;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {       // transposed product (W fragment first): a lane holds ONE row of a block and 4 consecutive columns
+                        f32x4& d = acc4[ih * 2 + i][jh * 2 + j];
+                        if constexpr (H) d = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bf[pb][j]), __builtin_bit_cast(f16x8, af[pa][i]), d, 0, 0, 0);
+                        else d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[pb][j], af[pa][i], d, 0, 0, 0);
+                    }
+            }
+    };
+    // per stage: the first quadrant's fragments (A blocks 0, 1; W blocks 0, 1: 8 reads) are fetched right after the barrier, the other 8 reads ride
+    // under the first quadrant's 12 MFMAs
+    bf16x8 fa0[NP][2], fa1[NP][2], fb0[NP][2], fb1[NP][2];
+    __syncthreads();   // prologue barrier: LDS tiles 0 .. AHEAD-1 are complete
+    if (nt > 0) { read_a(0, 0, fa0); read_b(0, 0, fb0); }
+    for (int t = 0; t < nt; ++t) {
+        read_a(t, 1, fa1);
+        read_b(t, 1, fb1);
+        mfma_quad(fa0, fb0, 0, 0);
+        mfma_quad(fa1, fb0, 1, 0);
+        mfma_quad(fa0, fb1, 0, 1);
+        mfma_quad(fa1, fb1, 1, 1);
+        __syncthreads();
+        if (t + 1 < nt) { read_a(t + 1, 0, fa0); read_b(t + 1, 0, fb0); }
+    }
+    // the C tile image (see the 32 x 32 form below): row = the lane's row of the block, columns 4 (lane >> 4) .. + 3
+    float* ctile = reinterpret_cast<float*>(smem_raw);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<f32x4*>(ctile + (wm * WTM + i * 16 + r16) * EP_LD + wn * WTN + j * 16 + 4 * kc) = acc4[i][j];
     } else {
     // ---- consumers ----
 #pragma unroll
